@@ -1,0 +1,127 @@
+"""CPU oracle: the CycleGAN generator / discriminator / train step from stock torch.nn.
+
+TEST INFRASTRUCTURE — not product code.  Nothing under unpaired-image-generation_amd/
+imports this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+
+Provenance.  The reference snapshot holds one file (/root/reference/README.md:1, a
+title) and no source, tests or golden vectors, so there is no reference function to
+follow line by line.  PARITY UNPINNED BY THE REFERENCE: the spec of record is
+SURVEY.md Appendix A (architecture) + §3.1 (step order), restated here with the stock
+torch CPU operators (torch==2.10.0+rocm7.0, ATen native + oneDNN) that define the
+arithmetic at the operator boundary of SURVEY.md §8(b).  What pins this oracle instead:
+  * SURVEY.md Appendix B known answers (param counts, config-1 output values / hashes,
+    the 8 first-step losses)  -> tests/test_oracle.py
+  * an independent fp64 numpy restatement of every operator (oracle/naive_fp64.py)
+    -> tests/test_oracle.py
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class ResBlock(nn.Module):
+    """x + [ReflPad1, Conv3x3, IN, ReLU, ReflPad1, Conv3x3, IN](x)   (SURVEY.md Appendix A)."""
+
+    def __init__(self, dim: int):
+        super().__init__()
+        self.b = nn.Sequential(
+            nn.ReflectionPad2d(1),
+            nn.Conv2d(dim, dim, 3, 1, 0, bias=True),
+            nn.InstanceNorm2d(dim, eps=1e-5, affine=False, track_running_stats=False),
+            nn.ReLU(True),
+            nn.ReflectionPad2d(1),
+            nn.Conv2d(dim, dim, 3, 1, 0, bias=True),
+            nn.InstanceNorm2d(dim, eps=1e-5, affine=False, track_running_stats=False),
+        )
+
+    def forward(self, x):
+        return x + self.b(x)
+
+
+def Generator(in_ch: int = 3, out_ch: int = 3, ngf: int = 64, n_blocks: int = 9) -> nn.Sequential:
+    """ResNet generator, SURVEY.md Appendix A.  state_dict keys '{idx}.weight', '{idx}.b.{j}.weight'."""
+    IN = lambda c: nn.InstanceNorm2d(c, eps=1e-5, affine=False, track_running_stats=False)
+    layers = [nn.ReflectionPad2d(3), nn.Conv2d(in_ch, ngf, 7, 1, 0, bias=True), IN(ngf), nn.ReLU(True),
+              nn.Conv2d(ngf, ngf * 2, 3, 2, 1, bias=True), IN(ngf * 2), nn.ReLU(True),
+              nn.Conv2d(ngf * 2, ngf * 4, 3, 2, 1, bias=True), IN(ngf * 4), nn.ReLU(True)]
+    layers += [ResBlock(ngf * 4) for _ in range(n_blocks)]
+    layers += [nn.ConvTranspose2d(ngf * 4, ngf * 2, 3, 2, 1, output_padding=1, bias=True), IN(ngf * 2), nn.ReLU(True),
+               nn.ConvTranspose2d(ngf * 2, ngf, 3, 2, 1, output_padding=1, bias=True), IN(ngf), nn.ReLU(True),
+               nn.ReflectionPad2d(3), nn.Conv2d(ngf, out_ch, 7, 1, 0, bias=True), nn.Tanh()]
+    return nn.Sequential(*layers)
+
+
+def Discriminator(in_ch: int = 3, ndf: int = 64, n_layers: int = 3) -> nn.Sequential:
+    """70x70 PatchGAN, SURVEY.md Appendix A (no sigmoid: LSGAN)."""
+    IN = lambda c: nn.InstanceNorm2d(c, eps=1e-5, affine=False, track_running_stats=False)
+    layers = [nn.Conv2d(in_ch, ndf, 4, 2, 1), nn.LeakyReLU(0.2, True)]
+    nf = 1
+    for n in range(1, n_layers):
+        nf_prev, nf = nf, min(2 ** n, 8)
+        layers += [nn.Conv2d(ndf * nf_prev, ndf * nf, 4, 2, 1, bias=True), IN(ndf * nf), nn.LeakyReLU(0.2, True)]
+    nf_prev, nf = nf, min(2 ** n_layers, 8)
+    layers += [nn.Conv2d(ndf * nf_prev, ndf * nf, 4, 1, 1, bias=True), IN(ndf * nf), nn.LeakyReLU(0.2, True)]
+    layers += [nn.Conv2d(ndf * nf, 1, 4, 1, 1)]
+    return nn.Sequential(*layers)
+
+
+def init_weights(net: nn.Module) -> nn.Module:
+    """conv / convT weights N(0, 0.02), biases 0, in net.modules() order (Appendix B recipe B1)."""
+    for m in net.modules():
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            nn.init.normal_(m.weight, 0.0, 0.02)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+    return net
+
+
+class CycleGANOracle:
+    """The §3.1 train step on stock torch CPU ops.  lambda=10, identity 0.5, LSGAN, Adam(2e-4, .5, .999)."""
+
+    def __init__(self, n_blocks: int = 9, lr: float = 2e-4, lambda_cyc: float = 10.0, lambda_idt: float = 0.5,
+                 dtype=torch.float32):
+        # Appendix B recipe B2: construct all four (default inits consume RNG), then re-init in this order.
+        self.G_A, self.G_B = Generator(n_blocks=n_blocks), Generator(n_blocks=n_blocks)
+        self.D_A, self.D_B = Discriminator(), Discriminator()
+        for n in self.nets():
+            init_weights(n).to(dtype)
+        self.lam, self.lam_idt = lambda_cyc, lambda_idt
+        self.opt_G = torch.optim.Adam(list(self.G_A.parameters()) + list(self.G_B.parameters()), lr=lr, betas=(0.5, 0.999))
+        self.opt_D = torch.optim.Adam(list(self.D_A.parameters()) + list(self.D_B.parameters()), lr=lr, betas=(0.5, 0.999))
+
+    def nets(self):
+        return (self.G_A, self.G_B, self.D_A, self.D_B)
+
+    @staticmethod
+    def _req(nets, flag):
+        for n in nets:
+            for p in n.parameters():
+                p.requires_grad_(flag)
+
+    def train_step(self, real_A: torch.Tensor, real_B: torch.Tensor) -> dict:
+        mse = lambda p, t: F.mse_loss(p, torch.full_like(p, t))
+        fake_B = self.G_A(real_A); rec_A = self.G_B(fake_B)
+        fake_A = self.G_B(real_B); rec_B = self.G_A(fake_A)
+        # --- generators (D frozen)
+        self._req((self.D_A, self.D_B), False)
+        self.opt_G.zero_grad()
+        idt_A = self.G_A(real_B); idt_B = self.G_B(real_A)
+        l_idt_A = F.l1_loss(idt_A, real_B) * self.lam * self.lam_idt
+        l_idt_B = F.l1_loss(idt_B, real_A) * self.lam * self.lam_idt
+        l_G_A = mse(self.D_A(fake_B), 1.0)
+        l_G_B = mse(self.D_B(fake_A), 1.0)
+        l_cyc_A = F.l1_loss(rec_A, real_A) * self.lam
+        l_cyc_B = F.l1_loss(rec_B, real_B) * self.lam
+        (l_G_A + l_G_B + l_cyc_A + l_cyc_B + l_idt_A + l_idt_B).backward()
+        self.opt_G.step()
+        # --- discriminators
+        self._req((self.D_A, self.D_B), True)
+        self.opt_D.zero_grad()
+        l_D_A = 0.5 * (mse(self.D_A(real_B), 1.0) + mse(self.D_A(fake_B.detach()), 0.0)); l_D_A.backward()
+        l_D_B = 0.5 * (mse(self.D_B(real_A), 1.0) + mse(self.D_B(fake_A.detach()), 0.0)); l_D_B.backward()
+        self.opt_D.step()
+        self.last = dict(fake_B=fake_B.detach(), fake_A=fake_A.detach(), rec_A=rec_A.detach(), rec_B=rec_B.detach())
+        return {"idt_A": l_idt_A.item(), "idt_B": l_idt_B.item(), "G_A": l_G_A.item(), "G_B": l_G_B.item(),
+                "cyc_A": l_cyc_A.item(), "cyc_B": l_cyc_B.item(), "D_A": l_D_A.item(), "D_B": l_D_B.item()}
