@@ -1,0 +1,159 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of the full CycleGAN train step (3x256x256) on N MI355X, one process per GPU.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one full optimisation step on a per-GPU batch of `--batch` (default 4: BASELINE.json
+configs[1]) synthetic (real_A, real_B) pairs; value = global pairs / second (weak scaling).  Rank 0 prints ONE JSON line
+with the contract fields plus `roofline` (dominant kernel: the 256->256 3x3 ResBlock convolution, HIP-event timed
+here) and, at N=1, `cpu_baseline` (the CPU oracle's train step on this host's cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F_G256 = 99.10e9      # generator forward FLOPs / image @256^2 (hook-counted on the oracle)
+F_D256 = 6.29e9       # discriminator forward FLOPs / image
+PEAK_BF16 = 2.5e15    # dense bf16 MFMA peak (MI355X_MICROARCH.md: Chip-level parameters)
+PEAK_F32 = 157.3e12
+
+
+def step_flops(size, n_blocks=9):
+    s = (size / 256.0) ** 2
+    return (18 * F_G256 + 16 * F_D256) * s if n_blocks == 9 else None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="pairs per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-iters", type=int, default=50)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import unpaired_image_generation_amd as u
+    assert u.lib.lib().uig_device_ok() == 1, "bench.py needs an MI355X (gfx950)"
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)                                   # identical replicas on every rank
+    model = u.CycleGAN(n_blocks=9, dtype=dtype, device=dev, use_graph=not args.no_graph)
+    model.broadcast_params(0)
+    torch.manual_seed(1000 + rank)                         # different data shard per rank
+    B, S = args.batch, args.size
+    real_A = torch.rand(B, 3, S, S, device=dev) * 2 - 1
+    real_B = torch.rand(B, 3, S, S, device=dev) * 2 - 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        model.train_step(real_A, real_B, sync=False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.train_step(real_A, real_B, sync=False)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = model.train_step(real_A, real_B)              # also proves the step still produces finite losses
+    assert all(v == v for v in losses.values()), losses
+
+    ms = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+    sf = step_flops(S)
+    out = {
+        "metric": "images/sec full CycleGAN train step, 3x256x256", "value": round(value, 3), "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"CycleGAN train step: 9-block G_A/G_B + 70x70 PatchGAN D_A/D_B, {S}x{S}, "
+                               f"batch {B}/GPU, {args.dtype} MFMA conv path, fp32 master weights + Adam",
+                   "global_batch": world * B, "image": f"3x{S}x{S}", "parallelism": f"dp{world}",
+                   "hip_graph": not args.no_graph},
+        "step_tflops": round(sf * B / (ms * 1e-3) / 1e12, 2),
+        "step_mfma_frac": round(sf * B / (ms * 1e-3) / (PEAK_BF16 if args.dtype == "bf16" else PEAK_F32), 4),
+        "losses": {k: round(v, 4) for k, v in losses.items()},
+    }
+    if rank == 0:
+        out["roofline"] = dominant_kernel_roofline(u, torch, dev, dtype, 2 * B, S // 4, args.kernel_iters)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(torch, S)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def dominant_kernel_roofline(u, torch, dev, dtype, nimg, hw, iters):
+    """The ResBlock 3x3 reflect-pad conv (256->256 on hw x hw, the batch-2B launch the step issues): 88 % of generator
+    FLOPs.  HIP events (torch.cuda.Event on the launch stream) around `iters` back-to-back launches on random data."""
+    from unpaired_image_generation_amd import ops, networks
+    layer = networks.ConvLayer("conv", 256, 256, 3, 1, 1, "reflect", dtype=dtype, device=dev)
+    layer.repack()
+    x = (torch.rand(nimg, hw, hw, 256, device=dev) * 2 - 1).to(dtype)
+    for _ in range(5):
+        ops.conv_forward(layer.spec, x, layer.wp_fwd, layer.bias)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.conv_forward(layer.spec, x, layer.wp_fwd, layer.bias)
+    e1.record()
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    flops = 2.0 * nimg * hw * hw * 256 * 2304
+    peak = PEAK_BF16 if dtype == torch.bfloat16 else PEAK_F32
+    ach = flops / (us * 1e-6)
+    return {"kernel": "igemm_kernel<bf16,128,128> conv3x3 256->256 reflect (ResBlock fwd)" if dtype == torch.bfloat16 else "igemm_kernel<f32,128,128>",
+            "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": None, "avg_us": round(us, 2),
+            "gemm": f"M={nimg * hw * hw} N=256 K=2304", "flops_per_launch": flops}
+
+
+def cpu_baseline(torch, size):
+    """The CPU oracle's train step (stock torch fp32) on this host's cores: 1 warm-up + 2 timed steps at B=1."""
+    from oracle.torch_oracle import CycleGANOracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    o = CycleGANOracle(n_blocks=9)
+    rA = torch.rand(1, 3, size, size) * 2 - 1
+    rB = torch.rand(1, 3, size, size) * 2 - 1
+    o.train_step(rA, rB)
+    t0 = time.perf_counter()
+    n = 2
+    for _ in range(n):
+        o.train_step(rA, rB)
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"CPU oracle (stock torch {torch.__version__} fp32) full train step, B=1 {size}x{size}, 1 warm-up + {n} timed steps"}
+
+
+if __name__ == "__main__":
+    main()

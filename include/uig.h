@@ -1,0 +1,119 @@
+/*
+ * uig.h — C ABI of the MI355X-native CycleGAN train-step hot path (libuig.so).
+ *
+ * Drop-in boundary.  The reference snapshot defines no FFI of its own
+ * (/root/reference/README.md:1 is the whole tree), so every entry point below names the
+ * ATen operator schema (torch 2.10) whose arithmetic it replaces on the GPU.
+ *
+ * Conventions
+ *   - plain pointers + ints, no torch types; every pointer is DEVICE memory owned by the caller
+ *     (torch's caching allocator); the library allocates nothing and keeps no pointer past return.
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*).
+ *   - return 0 = ok; negative = argument error (nothing launched, message in uig_last_error());
+ *     positive = hipError_t of the failed launch.
+ *   - activations: NHWC, channel count physically padded to a multiple of 8 (pad channels are 0);
+ *     dtype: UIG_F32 (exact-f32 MFMA path, the L-inf < 1e-3 parity path) or UIG_BF16.
+ *   - weights at the boundary: the torch layouts, fp32 (Conv2d: O,I,kH,kW; ConvTranspose2d: I,O,kH,kW);
+ *     uig_pack_weight() produces the kernel-side [N][tap][C] operand in the compute dtype.
+ */
+#ifndef UIG_H
+#define UIG_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { UIG_F32 = 0, UIG_BF16 = 1 };
+enum { UIG_ACT_NONE = 0, UIG_ACT_RELU = 1, UIG_ACT_LRELU = 2, UIG_ACT_TANH = 3 };
+enum { UIG_PAD_ZERO = 0, UIG_PAD_REFLECT = 1 };
+/* gather modes of uig_conv_gather: direct = strided cross-correlation (conv fwd, convT dgrad);
+ * transposed = fractionally-strided gather in stride*stride sub-pixel phases (convT fwd, conv dgrad). */
+enum { UIG_GATHER_DIRECT = 0, UIG_GATHER_TRANSPOSED = 1 };
+/* weight packing: A: out[d0][tap][d1] (row = dim0 of the torch weight), B: out[d1][tap][d0], taps flipped=0/1 */
+enum { UIG_PACK_ROW_DIM0 = 0, UIG_PACK_ROW_DIM1 = 1 };
+
+const char* uig_version(void);
+const char* uig_last_error(void);
+int uig_device_ok(void); /* 1 if a gfx950 device is visible to the HIP runtime */
+
+/* aten::convolution / aten::convolution_backward(input grad) — implicit GEMM, LDS-staged im2col tiles -> MFMA.
+ *   y[b, oh, ow, n] = act( bias[n] + sum_{tap,c} x[b, ih(tap), iw(tap), c] * wp[n][tap][c] )
+ * direct:      ih = oh*stride + kh - pad            (pad_mode zero or reflect),   y is Ho x Wo
+ * transposed:  oh = ih*stride - pad + kh  (all (ih,kh) pairs that hit oh; zero outside), y is Ho x Wo
+ * x: (B,H,W,Cin) NHWC, Cin % 8 == 0;  wp: packed [Nrows][kH*kW][Cin];  y: (B,Ho,Wo,ldc), channels n < Nstore written
+ * (rows n >= Nrows of wp are treated as zero).  bias may be NULL (fp32[>=Nstore]).                              */
+int uig_conv_gather(const void* x, const void* wp, const float* bias, void* y,
+                    int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
+                    int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
+                    int act, float slope, int dtype, void* stream);
+
+/* aten::convolution_backward(weight grad) — dW partials by split-K MFMA GEMM over pixels, then uig_wgrad_reduce.
+ *   part[s][n][tap][c] = sum_{pixels m in split s} P[m][n] * Q[pix(m,tap)][c]
+ * P: dense operand (B,Mh,Mw,Np) (dy for Conv2d, x for ConvTranspose2d); Q: gathered operand (B,Hq,Wq,Cq) read at
+ * (i*stride + kh - pad, j*stride + kw - pad) with zero/reflect padding.  workspace: fp32[splits*Np*kH*kW*Cq].   */
+size_t uig_wgrad_workspace_bytes(int Np, int Cq, int kH, int kW, int splits);
+int uig_wgrad_partial(const void* P, const void* Q, float* workspace, int B, int Mh, int Mw, int Np,
+                      int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int pad_mode,
+                      int splits, int dtype, void* stream);
+/* dW[d0][d1][tap] (+)= sum_s part[s][d0][tap][d1]  for d0 < D0, d1 < D1 (the real, unpadded channel counts) */
+int uig_wgrad_reduce(const float* workspace, float* dW, int Np, int Cq, int taps, int splits,
+                     int D0, int D1, int accumulate, void* stream);
+/* db[n] (+)= sum over all B*H*W pixels of dy[m][n], n < Nreal (aten::convolution_backward bias grad).
+ * workspace: fp32[uig_colsum_workspace_floats(C)] */
+size_t uig_colsum_workspace_floats(int C);
+int uig_bias_grad(const void* dy, float* db, float* workspace, int64_t pixels, int C, int Nreal,
+                  int accumulate, int dtype, void* stream);
+
+/* fp32 torch-layout weight (D0,D1,kH,kW) -> packed [rows_padded][taps][cols_padded] in `dtype`, zero padded.
+ * row_dim selects which torch dim becomes the GEMM row (UIG_PACK_ROW_DIM0 / _DIM1); flip=1 reverses taps. */
+int uig_pack_weight(const float* w, void* wp, int D0, int D1, int kH, int kW, int row_dim, int flip,
+                    int rows_padded, int cols_padded, int dtype, void* stream);
+
+/* aten::instance_norm(use_input_stats=True, weight=None, eps) fused with ReLU / LeakyReLU and residual add:
+ *   y = act((x - mean_bc) * rstd_bc) + (residual ? residual : 0);  stats fp32[B*C*2] = (mean, rstd) saved for bwd.
+ * workspace: fp32[uig_instnorm_workspace_floats(B,HW,C)].                                                    */
+size_t uig_instnorm_workspace_floats(int B, int64_t HW, int C);
+int uig_instnorm_act_fwd(const void* x, const void* residual, void* y, float* stats, float* workspace,
+                         int B, int64_t HW, int C, float eps, int act, float slope, int dtype, void* stream);
+/* aten::native_batch_norm_backward (on the (1,B*C,H,W) view) fused with the activation's backward:
+ *   g = dy * act'(xhat);  dx = rstd * (g - mean(g) - xhat * mean(g*xhat))                                   */
+int uig_instnorm_act_bwd(const void* dy, const void* x, const float* stats, void* dx, float* workspace,
+                         int B, int64_t HW, int C, int act, float slope, int dtype, void* stream);
+
+/* aten::reflection_pad2d_backward: fold (B,H+2p,W+2p,C) -> (B,H,W,C) */
+int uig_reflect_fold(const void* dyp, void* dx, int B, int H, int W, int C, int pad, int dtype, void* stream);
+/* aten::tanh_backward / leaky_relu_backward / threshold_backward on the activation OUTPUT y: dx = dy * act'(y) */
+int uig_act_bwd(const void* dy, const void* y, void* dx, int64_t n, int act, float slope, int dtype, void* stream);
+
+/* aten::l1_loss(mean) forward + gradient in one pass:  loss[0] = weight*mean|a-b| over n_real elements;
+ * grad_a = weight*sign(a-b)/n_real (may be NULL).  n = physical element count (padded channels are 0 in both). */
+int uig_l1_loss_fwd_bwd(const void* a, const void* b, float* loss, void* grad_a, float* workspace,
+                        int64_t n, int64_t n_real, float weight, int dtype, void* stream);
+/* aten::mse_loss(a, full_like(a, target), mean) + gradient: loss = weight*mean((a-t)^2); grad = weight*2(a-t)/n */
+int uig_mse_const_fwd_bwd(const void* a, float target, float* loss, void* grad_a, float* workspace,
+                          int64_t n, float weight, int dtype, void* stream);
+size_t uig_loss_workspace_floats(void);
+/* g_out = g * scalar[0]  (loss backward when the upstream gradient is a device scalar) */
+int uig_scale_by_scalar(const void* g, const float* scalar, void* g_out, int64_t n, int dtype, void* stream);
+
+/* aten::_fused_adam (amsgrad=False, maximize=False, weight_decay=0) over one flat fp32 buffer.
+ * g is multiplied by grad_scale first (1/world_size after an all-reduce(sum)). step = 1,2,... */
+int uig_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int step, float grad_scale, void* stream);
+
+/* Same update, replayable from a HIP graph: the step counter and bias-correction scalars live in the 16-byte device
+ * record state16 = {int step; float lr/bc1; float 1/sqrt(bc2); pad}; each call increments step on the device. */
+int uig_adam_flat_graph(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                        float eps, void* state16, float grad_scale, void* stream);
+
+/* layout plumbing at the module surface: arbitrary-strided fp32/bf16 (B,C,H,W) logical tensor <-> NHWC(Cp) */
+int uig_to_nhwc(const void* src, int src_dtype, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                void* dst, int B, int C, int H, int W, int Cp, int dtype, void* stream);
+int uig_from_nhwc(const void* src, int B, int C, int H, int W, int Cp, int dtype,
+                  void* dst, int dst_dtype, int64_t sb, int64_t sc, int64_t sh, int64_t sw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UIG_H */

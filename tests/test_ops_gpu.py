@@ -1,0 +1,211 @@
+"""GPU parity tests: every HIP op (forward AND backward) through the C ABI vs the CPU oracle (stock torch ops) on the
+same seeded inputs.  fp32 path: exact-f32 MFMA, tight tolerance.  bf16 path: compared with the oracle evaluated on
+bf16-rounded operands (fp32 accumulate), tolerance = a few bf16 ulps of the output scale (stated per test)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    import unpaired_image_generation_amd as u
+    from unpaired_image_generation_amd import ops, networks
+    assert u.lib.lib().uig_device_ok() == 1, "no gfx950 device visible"
+    return u, ops, networks
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _tol(dtype, ref):
+    scale = float(ref.abs().max()) + 1e-6
+    return (2e-5 * scale + 1e-6) if dtype == torch.float32 else (1.6e-2 * scale)
+
+
+CONV_CASES = [
+    # kind, cin, cout, k, s, p, pad_mode, H, W, B      (the layer shapes of Appendix A at small spatial size)
+    ("conv", 3, 64, 7, 1, 3, "reflect", 20, 24, 2),     # G layer 1 (Cin=3 -> small-Cin gather)
+    ("conv", 64, 128, 3, 2, 1, "zero", 24, 20, 2),      # G downsample
+    ("conv", 128, 256, 3, 2, 1, "zero", 12, 16, 1),
+    ("conv", 256, 256, 3, 1, 1, "reflect", 12, 10, 3),  # ResBlock conv (the 88 % shape), ragged M
+    ("convT", 256, 128, 3, 2, 1, "zero", 6, 8, 2),      # upsample
+    ("convT", 128, 64, 3, 2, 1, "zero", 10, 6, 1),
+    ("conv", 64, 3, 7, 1, 3, "reflect", 18, 22, 2),     # G head (Cout=3 -> BN=16 tile)
+    ("conv", 3, 64, 4, 2, 1, "zero", 32, 24, 2),        # D layer 1
+    ("conv", 64, 128, 4, 2, 1, "zero", 16, 16, 2),
+    ("conv", 256, 512, 4, 1, 1, "zero", 9, 8, 2),       # D layer 4 (odd output 8x7)
+    ("conv", 512, 1, 4, 1, 1, "zero", 8, 9, 2),         # D head (Cout=1, unpadded output)
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"{c[0]}{c[1]}-{c[2]}k{c[3]}s{c[4]}{c[6][0]}")
+def test_conv_fwd_bwd(case, dtype):
+    u, ops, networks = _mods()
+    kind, cin, cout, k, s, p, pm, H, W, B = case
+    torch.manual_seed(hash(case) % 1000)
+    layer = networks.ConvLayer(kind, cin, cout, k, s, p, pm, dtype=dtype, device="cuda")
+    w = torch.randn(layer.spec.weight_shape()) * 0.05
+    b = torch.randn(cout) * 0.1
+    with torch.no_grad():
+        layer.weight.copy_(w); layer.bias.copy_(b)
+    x = torch.rand(B, cin, H, W) * 2 - 1
+    rnd = _bf if dtype == torch.bfloat16 else (lambda t: t)
+    xr = rnd(x).requires_grad_(True); wr = rnd(w).requires_grad_(True); br = b.clone().requires_grad_(True)
+    xin = F.pad(xr, (p, p, p, p), mode="reflect") if pm == "reflect" else xr
+    if kind == "conv":
+        yref = F.conv2d(xin, wr, br, s, 0 if pm == "reflect" else p)
+    else:
+        yref = F.conv_transpose2d(xin, wr, br, s, p, output_padding=1)
+    xp = ops.to_nhwc(x.cuda(), dtype).requires_grad_(True)
+    yp = layer(xp)
+    y = ops.from_nhwc(yp, cout).cpu()
+    assert y.shape == yref.shape
+    assert (y - yref.detach()).abs().max() <= _tol(dtype, yref), f"fwd L-inf {(y - yref.detach()).abs().max()}"
+    if yp.shape[3] > cout:
+        assert float(yp[..., cout:].abs().max()) == 0.0, "padded output channels must be zero"
+    # backward
+    dy = torch.randn_like(yref) * 0.5
+    dyr = rnd(dy)
+    yref.backward(dyr)
+    dyp = ops.to_nhwc(dy.cuda(), dtype, yp.shape[3])
+    yp.backward(dyp)
+    dx = ops.from_nhwc(xp.grad, cin).cpu()
+    assert (dx - xr.grad).abs().max() <= _tol(dtype, xr.grad), f"dgrad L-inf {(dx - xr.grad).abs().max()}"
+    if xp.grad.shape[3] > cin:
+        assert float(xp.grad[..., cin:].abs().max()) == 0.0
+    dW = layer.weight.grad.cpu()
+    assert (dW - wr.grad).abs().max() <= _tol(dtype, wr.grad), f"wgrad L-inf {(dW - wr.grad).abs().max()} of {wr.grad.abs().max()}"
+    db = layer.bias.grad.cpu()
+    assert (db - br.grad).abs().max() <= _tol(dtype, br.grad) * 2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("act", ["tanh", "lrelu"])
+def test_conv_epilogue_activation(act, dtype):
+    u, ops, networks = _mods()
+    L = u.lib
+    torch.manual_seed(3)
+    a = L.ACT_TANH if act == "tanh" else L.ACT_LRELU
+    layer = networks.ConvLayer("conv", 64, 3 if act == "tanh" else 64, 3, 1, 1, "zero", act=a, slope=0.2, dtype=dtype, device="cuda")
+    cout = layer.spec.cout
+    rnd = _bf if dtype == torch.bfloat16 else (lambda t: t)
+    x = torch.rand(2, 64, 10, 12) * 2 - 1
+    w = layer.weight.detach().cpu() * 5
+    with torch.no_grad():
+        layer.weight.copy_(w)
+    xr = rnd(x).requires_grad_(True); wr = rnd(w).requires_grad_(True)
+    pre = F.conv2d(xr, wr, layer.bias.detach().cpu(), 1, 1)
+    yref = torch.tanh(pre) if act == "tanh" else F.leaky_relu(pre, 0.2)
+    xp = ops.to_nhwc(x.cuda(), dtype).requires_grad_(True)
+    yp = layer(xp)
+    assert (ops.from_nhwc(yp, cout).cpu() - yref.detach()).abs().max() <= _tol(dtype, yref)
+    dy = torch.randn_like(yref)
+    yref.backward(rnd(dy))
+    yp.backward(ops.to_nhwc(dy.cuda(), dtype, yp.shape[3]))
+    assert (ops.from_nhwc(xp.grad, 64).cpu() - xr.grad).abs().max() <= _tol(dtype, xr.grad) * 2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape,act,res", [((2, 256, 16, 12), "relu", False), ((3, 256, 8, 8), "none", True),
+                                           ((2, 64, 40, 36), "relu", False), ((2, 512, 31, 31), "lrelu", False),
+                                           ((1, 128, 33, 17), "lrelu", False)])
+def test_instnorm_fwd_bwd(shape, act, res, dtype):
+    u, ops, networks = _mods()
+    L = u.lib
+    torch.manual_seed(5)
+    B, C, H, W = shape
+    a = {"relu": L.ACT_RELU, "lrelu": L.ACT_LRELU, "none": L.ACT_NONE}[act]
+    rnd = _bf if dtype == torch.bfloat16 else (lambda t: t)
+    x = torch.randn(shape) * 2 + 0.5
+    r = torch.randn(shape)
+    xr = rnd(x).requires_grad_(True); rr = rnd(r).requires_grad_(True)
+    y = F.instance_norm(xr, eps=1e-5)
+    y = F.relu(y) if act == "relu" else (F.leaky_relu(y, 0.2) if act == "lrelu" else y)
+    if res:
+        y = y + rr
+    xp = ops.to_nhwc(x.cuda(), dtype).requires_grad_(True)
+    rp = ops.to_nhwc(r.cuda(), dtype).requires_grad_(True) if res else None
+    mod = networks.InstNormAct(a, 0.2)
+    yp = mod(xp, rp)
+    tol = 2e-5 * 6 if dtype == torch.float32 else 4e-2
+    assert (ops.from_nhwc(yp, C).cpu() - y.detach()).abs().max() <= tol
+    dy = torch.randn(shape)
+    y.backward(rnd(dy))
+    yp.backward(ops.to_nhwc(dy.cuda(), dtype))
+    tolb = 1e-4 if dtype == torch.float32 else 4e-2 * float(xr.grad.abs().max() + 1)
+    assert (ops.from_nhwc(xp.grad, C).cpu() - xr.grad).abs().max() <= tolb
+    if res:
+        assert (ops.from_nhwc(rp.grad, C).cpu() - rr.grad).abs().max() <= tolb
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_losses(dtype):
+    u, ops, networks = _mods()
+    torch.manual_seed(9)
+    rnd = _bf if dtype == torch.bfloat16 else (lambda t: t)
+    a, b = torch.rand(2, 3, 20, 24) * 2 - 1, torch.rand(2, 3, 20, 24) * 2 - 1
+    ar = rnd(a).requires_grad_(True)
+    lref = F.l1_loss(ar, rnd(b)) * 10.0
+    (lref * 0.7).backward()
+    ap = ops.to_nhwc(a.cuda(), dtype).requires_grad_(True)
+    l = ops.l1_loss(ap, ops.to_nhwc(b.cuda(), dtype), 10.0, a.numel())
+    (l * 0.7).backward()
+    assert abs(l.item() - lref.item()) < 1e-5 * max(1, abs(lref.item()))
+    g = ops.from_nhwc(ap.grad, 3).cpu()
+    assert (g - ar.grad).abs().max() <= (1e-9 if dtype == torch.float32 else 1e-2 * float(ar.grad.abs().max()))
+    # LSGAN loss on an unpadded 1-channel patch map whose size is not a multiple of the 16-byte chunk
+    p = torch.randn(3, 1, 7, 9)
+    pr = rnd(p).requires_grad_(True)
+    for t, wgt in ((1.0, 1.0), (0.0, 0.5)):
+        pr.grad = None
+        lref = F.mse_loss(pr, torch.full_like(pr, t)) * wgt
+        lref.backward()
+        pp = ops.to_nhwc(p.cuda(), dtype, 8)[..., :1].contiguous().requires_grad_(True)
+        l = ops.mse_const(pp, t, wgt)
+        l.backward()
+        assert abs(l.item() - lref.item()) < 1e-5 * max(1, abs(lref.item()))
+        g = pp.grad.permute(0, 3, 1, 2).float().cpu()
+        assert (g - pr.grad).abs().max() <= (1e-8 if dtype == torch.float32 else 1e-2 * float(pr.grad.abs().max()))
+
+
+def test_adam_flat_matches_torch():
+    u, ops, networks = _mods()
+    torch.manual_seed(11)
+    n = 10007
+    p0 = torch.randn(n)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=2e-4, betas=(0.5, 0.999), eps=1e-8)
+    p = p0.cuda(); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    p2 = p0.cuda(); m2 = torch.zeros(n, device="cuda"); v2 = torch.zeros(n, device="cuda")
+    st = torch.zeros(4, dtype=torch.int32, device="cuda")
+    for step in (1, 2, 3, 4):
+        g = torch.randn(n) * (10.0 ** (step - 3))
+        pr.grad = g.clone(); opt.step()
+        ops.adam_flat(p, (g * 2).cuda(), m, v, 2e-4, 0.5, 0.999, 1e-8, step, 0.5)     # grad_scale folds 1/world
+        ops.adam_flat_graph(p2, g.cuda(), m2, v2, 2e-4, 0.5, 0.999, 1e-8, st, 1.0)
+        assert (p.cpu() - pr.detach()).abs().max() < 2e-7
+        assert (p2.cpu() - pr.detach()).abs().max() < 2e-7
+    assert int(st[0]) == 4
+
+
+def test_layout_roundtrip_and_reflect_fold():
+    u, ops, networks = _mods()
+    torch.manual_seed(13)
+    x = torch.randn(2, 3, 9, 11)
+    xp = ops.to_nhwc(x.cuda(), torch.float32)
+    assert xp.shape == (2, 9, 11, 8) and float(xp[..., 3:].abs().max()) == 0
+    assert torch.equal(ops.from_nhwc(xp, 3).cpu(), x)
+    xcl = x.cuda().contiguous(memory_format=torch.channels_last)        # arbitrary input strides
+    assert torch.equal(ops.to_nhwc(xcl, torch.float32), xp)
+    for P, H, W in ((1, 8, 10), (3, 7, 9), (3, 16, 8)):
+        dyp = torch.randn(2, 16, H + 2 * P, W + 2 * P)
+        ref = torch.zeros(2, 16, H, W, requires_grad=True)
+        F.pad(ref, (P, P, P, P), mode="reflect").backward(dyp)
+        dypp = ops.to_nhwc(dyp.cuda(), torch.float32)
+        dx = torch.empty(2, H, W, 16, device="cuda")
+        u.lib.check(u.lib.lib().uig_reflect_fold(dypp.data_ptr(), dx.data_ptr(), 2, H, W, 16, P, 0, torch.cuda.current_stream().cuda_stream), "fold")
+        assert (ops.from_nhwc(dx, 16).cpu() - ref.grad).abs().max() < 1e-5

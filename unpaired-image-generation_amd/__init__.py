@@ -1,0 +1,6 @@
+"""MI355X-native CycleGAN train-step hot path (gfx950 HIP kernels behind a C ABI)."""
+from . import lib, ops  # noqa: F401
+from .networks import Discriminator, Generator  # noqa: F401
+from .cyclegan import CycleGAN  # noqa: F401
+
+__all__ = ["Generator", "Discriminator", "CycleGAN", "lib"]

@@ -1,0 +1,321 @@
+// conv_igemm.hip — implicit-GEMM gather convolution for gfx950 (MI355X).
+//
+// One kernel serves Conv2d forward, ConvTranspose2d forward and both of their input gradients
+// (aten::convolution / aten::convolution_backward[input]); see uig_conv_gather in include/uig.h.
+//
+//   D[n][m] = sum_k  Wp[n][k] * X[pix(m, tap(k))][c(k)]        k = (tap, c),  c contiguous (NHWC)
+//
+// Layout in HBM: activations NHWC (channels padded to 8), packed weights [N][tap][C]: both operands are
+// K-contiguous, so every lane moves 16-byte chunks.  Per K-step the block stages a BM-pixel x 128-byte im2col tile
+// and a BN-channel x 128-byte weight tile through registers into XOR-swizzled LDS (double buffered, one barrier per
+// K-step), and each of the 4 waves runs MFMA 16x16 tiles over its WM x WN sub-tile:
+//   bf16: v_mfma_f32_16x16x32_bf16 (BK = 64),   f32: v_mfma_f32_16x16x4_f32 (BK = 32, exact f32 fmaf chain).
+// The weight tile is the MFMA A operand and the pixel tile the B operand, so each lane ends up holding 4
+// consecutive output channels of one pixel (8/16-byte stores into NHWC).
+// Reflection padding is resolved in the gather address map; zero padding by predication.
+#include "uig_common.h"
+
+struct GatherDesc {
+    int B, H, W, Cin;
+    int Mh, Mw;            // per-phase iteration grid (per image)
+    int si, so;            // input stride, output stride
+    int pad_mode;
+    int Nrows, ldw;
+    int Ho, Wo, ldc, Nstore;
+    int act; float slope;
+    int cin_shift;
+    int nphase;
+    int ph_tap0[5];
+    signed char ph_oh[4], ph_ow[4];
+    signed char dh[64], dw[64];
+    unsigned char wt[64];
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static __device__ __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static __device__ __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b[e]), c, 0, 0, 0);
+    }
+};
+
+template <typename T, int BM, int BN, int WAVES_M, bool SMALL_CIN>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const T* __restrict__ x, const T* __restrict__ wp,
+                                                        const float* __restrict__ bias, T* __restrict__ y,
+                                                        const GatherDesc d) {
+    constexpr int E = ElemTraits<T>::E;
+    constexpr int BK = 8 * E;                 // 128 bytes of K per row per step
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int MT = WM / 16, NT = WN / 16;
+    constexpr int RA = BM / 32, RB = (BN + 31) / 32;
+    constexpr int STAGE = (BM + BN) * 128;
+    static_assert(WM % 16 == 0 && WN % 16 == 0, "wave tile must be a multiple of the 16x16 MFMA tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = tid >> 3, ch = tid & 7;
+
+    // ---- tile coordinates (XCD-aware: blocks that share an XCD get a contiguous run of tiles)
+    const int nwg = gridDim.x;
+    int bid;
+    {
+        const int o = blockIdx.x, xcd = o & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (o >> 3);
+    }
+    const int ntn = (d.Nrows + BN - 1) / BN;
+    const int n_base = (bid % ntn) * BN, m_base = (bid / ntn) * BM;
+    const int ph = blockIdx.y;
+    const int tap0 = d.ph_tap0[ph], ntap = d.ph_tap0[ph + 1] - tap0;
+    const int M = d.B * d.Mh * d.Mw;
+    const int Cin = d.Cin;
+
+    // ---- per-thread row bookkeeping for the gather
+    int hb[RA], wb[RA], ib[RA];
+    unsigned vmask = 0;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m_base + lr + 32 * i;
+        const bool v = m < M;
+        const int mm = v ? m : 0;
+        const int jj = mm % d.Mw, t = mm / d.Mw, ii = t % d.Mh, b = t / d.Mh;
+        hb[i] = ii * d.si; wb[i] = jj * d.si; ib[i] = b * d.H * d.W;
+        vmask |= (v ? 1u : 0u) << i;
+    }
+    int wrow[RB];
+    unsigned nmask = 0;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int r = lr + 32 * i, n = n_base + r;
+        const bool v = (r < BN) && (n < d.Nrows);
+        wrow[i] = (v ? n : 0) * d.ldw;
+        nmask |= (v ? 1u : 0u) << i;
+    }
+
+    const int ktot = ntap * Cin;
+    const int nk = (ktot + BK - 1) / BK;
+
+    u32x4_t ra[RA], rb[RB];
+    int tap_l = 0, c0 = 0;   // running (tap, channel) of the K-step being loaded (non-small mode)
+
+    auto load_tile = [&](int ks) {
+        int tl, c;
+        if constexpr (SMALL_CIN) {
+            const int kf = ks * BK + ch * E;
+            tl = kf >> d.cin_shift; c = kf & (Cin - 1);
+        } else {
+            tl = tap_l; c = c0 + ch * E;
+            c0 += BK; if (c0 >= Cin) { c0 = 0; ++tap_l; }
+        }
+        const bool kok = tl < ntap;
+        const int tap = tap0 + (kok ? tl : 0);
+        const int ddh = d.dh[tap], ddw = d.dw[tap], wtap = d.wt[tap];
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            int hi = hb[i] + ddh, wi = wb[i] + ddw;
+            bool ok = kok && ((vmask >> i) & 1u);
+            if (d.pad_mode == UIG_PAD_REFLECT) { hi = reflect_idx(hi, d.H); wi = reflect_idx(wi, d.W); }
+            else ok = ok && ((unsigned)hi < (unsigned)d.H) && ((unsigned)wi < (unsigned)d.W);
+            const long off = ((long)(ib[i] + hi * d.W + wi)) * Cin + c;
+            u32x4_t z = {0u, 0u, 0u, 0u};
+            ra[i] = ok ? *reinterpret_cast<const u32x4_t*>(x + off) : z;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const bool ok = kok && ((nmask >> i) & 1u);
+            u32x4_t z = {0u, 0u, 0u, 0u};
+            rb[i] = ok ? *reinterpret_cast<const u32x4_t*>(wp + (long)wrow[i] + wtap * Cin + c) : z;
+        }
+    };
+    auto store_tile = [&](int stage) {
+        unsigned char* sx = smem + stage * STAGE;
+        unsigned char* sw = sx + BM * 128;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int r = lr + 32 * i;
+            *reinterpret_cast<u32x4_t*>(sx + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int r = lr + 32 * i;
+            if (r < BN) *reinterpret_cast<u32x4_t*>(sw + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4)) = rb[i];
+        }
+    };
+
+    f32x4_t acc[NT][MT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+    const int l16 = lane & 15, q = lane >> 4;
+    const int swz = (l16 >> 1) & 7;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < nk) load_tile(ks + 1);
+        const unsigned char* sx = smem + cur * STAGE + (wm * WM + l16) * 128;
+        const unsigned char* sw = smem + cur * STAGE + BM * 128 + (wn * WN + l16) * 128;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int co = ((q + 4 * t) ^ swz) << 4;
+            u32x4_t xf[MT], wf[NT];
+#pragma unroll
+            for (int b = 0; b < MT; ++b) xf[b] = *reinterpret_cast<const u32x4_t*>(sx + b * 16 * 128 + co);
+#pragma unroll
+            for (int a = 0; a < NT; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(sw + a * 16 * 128 + co);
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < MT; ++b) Mma<T>::run(wf[a], xf[b], acc[a][b]);
+        }
+        if (ks + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds channels n..n+3 (rows 4q+reg of the 16x16 tile) of pixel column l16
+    const int oh0 = d.ph_oh[ph], ow0 = d.ph_ow[ph];
+    const bool vec_ok = ((d.Nstore & 3) == 0) && ((d.ldc & 3) == 0);
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+        const int m = m_base + wm * WM + b * 16 + l16;
+        if (m >= M) continue;
+        const int jj = m % d.Mw, t = m / d.Mw, ii = t % d.Mh, bb = t / d.Mh;
+        const int ho = ii * d.so + oh0, wo = jj * d.so + ow0;
+        if (ho >= d.Ho || wo >= d.Wo) continue;
+        T* yp = y + ((long)(bb * d.Ho + ho) * d.Wo + wo) * d.ldc;
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            const int n = n_base + wn * WN + a * 16 + 4 * q;
+            if (n >= d.Nstore) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float bv = (bias != nullptr && n + e < d.Nrows) ? bias[n + e] : 0.f;
+                v[e] = apply_act(acc[a][b][e] + bv, d.act, d.slope);
+            }
+            if (vec_ok) {
+                if constexpr (sizeof(T) == 4) {
+                    *reinterpret_cast<f32x4_t*>(yp + n) = f32x4_t{v[0], v[1], v[2], v[3]};
+                } else {
+                    u32x2_t pk;
+                    pk[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                    pk[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                    *reinterpret_cast<u32x2_t*>(yp + n) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < d.Nstore) ElemTraits<T>::st(yp + n + e, v[e]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+template <typename T, int BM, int BN, int WAVES_M, bool SMALL>
+static int launch_igemm(const void* x, const void* wp, const float* bias, void* y, const GatherDesc& d, hipStream_t s) {
+    const int M = d.B * d.Mh * d.Mw;
+    const int mt = (M + BM - 1) / BM, nt = (d.Nrows + BN - 1) / BN;
+    const size_t smem = 2 * (size_t)(BM + BN) * 128;
+    auto kern = igemm_kernel<T, BM, BN, WAVES_M, SMALL>;
+    static bool attr_done = false;   // benign race: idempotent
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return uig_set_error((int)e, "igemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(mt * nt, d.nphase), dim3(256), smem, s,
+                       (const T*)x, (const T*)wp, bias, (T*)y, d);
+    UIG_LAUNCH_CHECK("uig_conv_gather");
+    return 0;
+}
+
+template <typename T>
+static int dispatch_igemm(const void* x, const void* wp, const float* bias, void* y, const GatherDesc& d, hipStream_t s) {
+    constexpr int BK = 8 * ElemTraits<T>::E;
+    const bool small = d.Cin < BK || (d.Cin % BK) != 0;
+    if (d.Nrows <= 16) {
+        return small ? launch_igemm<T, 256, 16, 4, true>(x, wp, bias, y, d, s)
+                     : launch_igemm<T, 256, 16, 4, false>(x, wp, bias, y, d, s);
+    } else if (d.Nrows <= 64) {
+        return small ? launch_igemm<T, 128, 64, 2, true>(x, wp, bias, y, d, s)
+                     : launch_igemm<T, 128, 64, 2, false>(x, wp, bias, y, d, s);
+    }
+    return small ? launch_igemm<T, 128, 128, 2, true>(x, wp, bias, y, d, s)
+                 : launch_igemm<T, 128, 128, 2, false>(x, wp, bias, y, d, s);
+}
+
+static int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+extern "C" int uig_conv_gather(const void* x, const void* wp, const float* bias, void* y,
+                               int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
+                               int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
+                               int act, float slope, int dtype, void* stream) {
+    UIG_CHECK_ARG(x && wp && y, "uig_conv_gather: null pointer");
+    UIG_CHECK_ARG(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "uig_conv_gather: bad shape B=%d H=%d W=%d Ho=%d Wo=%d", B, H, W, Ho, Wo);
+    UIG_CHECK_ARG(Cin >= 8 && Cin % 8 == 0, "uig_conv_gather: Cin=%d must be a multiple of 8 (pad channels)", Cin);
+    UIG_CHECK_ARG(kH >= 1 && kW >= 1 && kH * kW <= 64 && kH <= 8 && kW <= 8, "uig_conv_gather: unsupported kernel %dx%d", kH, kW);
+    UIG_CHECK_ARG(stride == 1 || stride == 2, "uig_conv_gather: stride=%d unsupported", stride);
+    UIG_CHECK_ARG(Nrows >= 1 && Nstore >= 1 && Nstore <= ldc, "uig_conv_gather: bad N (Nrows=%d Nstore=%d ldc=%d)", Nrows, Nstore, ldc);
+    UIG_CHECK_ARG(dtype == UIG_F32 || dtype == UIG_BF16, "uig_conv_gather: bad dtype %d", dtype);
+    UIG_CHECK_ARG((long)B * H * W * Cin < (1L << 31) && (long)B * Ho * Wo * ldc < (1L << 31), "uig_conv_gather: tensor too large for 32-bit pixel indexing");
+    if (pad_mode == UIG_PAD_REFLECT)
+        UIG_CHECK_ARG(gather_mode == UIG_GATHER_DIRECT && pad < H && pad < W, "uig_conv_gather: reflect pad needs direct mode and pad < dim");
+    const int BKe = (dtype == UIG_BF16) ? 64 : 32;
+    if (Cin < BKe || Cin % BKe) UIG_CHECK_ARG((Cin & (Cin - 1)) == 0, "uig_conv_gather: small Cin=%d must be a power of two", Cin);
+
+    GatherDesc d{};
+    d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.pad_mode = pad_mode;
+    d.Nrows = Nrows; d.ldw = kH * kW * Cin; d.Ho = Ho; d.Wo = Wo; d.ldc = ldc; d.Nstore = Nstore;
+    d.act = act; d.slope = slope;
+    d.cin_shift = 0; while ((1 << d.cin_shift) < Cin) ++d.cin_shift;
+    if (gather_mode == UIG_GATHER_DIRECT) {
+        UIG_CHECK_ARG(Ho == (H + 2 * pad - kH) / stride + 1 && Wo == (W + 2 * pad - kW) / stride + 1,
+                      "uig_conv_gather: direct output %dx%d does not match input %dx%d k=%dx%d s=%d p=%d", Ho, Wo, H, W, kH, kW, stride, pad);
+        d.nphase = 1; d.si = stride; d.so = 1; d.Mh = Ho; d.Mw = Wo;
+        d.ph_tap0[0] = 0; d.ph_tap0[1] = kH * kW; d.ph_oh[0] = 0; d.ph_ow[0] = 0;
+        for (int kh = 0; kh < kH; ++kh)
+            for (int kw = 0; kw < kW; ++kw) {
+                const int t = kh * kW + kw;
+                d.dh[t] = (signed char)(kh - pad); d.dw[t] = (signed char)(kw - pad); d.wt[t] = (unsigned char)t;
+            }
+    } else {
+        UIG_CHECK_ARG(gather_mode == UIG_GATHER_TRANSPOSED, "uig_conv_gather: bad gather_mode %d", gather_mode);
+        UIG_CHECK_ARG(Ho <= (H - 1) * stride - 2 * pad + kH + (stride - 1) && Wo <= (W - 1) * stride - 2 * pad + kW + (stride - 1),
+                      "uig_conv_gather: transposed output %dx%d too large for input %dx%d k=%dx%d s=%d p=%d", Ho, Wo, H, W, kH, kW, stride, pad);
+        d.nphase = stride * stride; d.si = 1; d.so = stride;
+        d.Mh = (Ho + stride - 1) / stride; d.Mw = (Wo + stride - 1) / stride;
+        int nt = 0;
+        for (int a = 0; a < stride; ++a)
+            for (int b = 0; b < stride; ++b) {
+                const int p = a * stride + b;
+                d.ph_tap0[p] = nt; d.ph_oh[p] = (signed char)a; d.ph_ow[p] = (signed char)b;
+                for (int kh = 0; kh < kH; ++kh) {
+                    if (((a + pad - kh) % stride + stride) % stride) continue;
+                    for (int kw = 0; kw < kW; ++kw) {
+                        if (((b + pad - kw) % stride + stride) % stride) continue;
+                        d.dh[nt] = (signed char)floordiv(a + pad - kh, stride);
+                        d.dw[nt] = (signed char)floordiv(b + pad - kw, stride);
+                        d.wt[nt] = (unsigned char)(kh * kW + kw);
+                        ++nt;
+                    }
+                }
+            }
+        d.ph_tap0[d.nphase] = nt;
+        for (int p = 0; p < d.nphase; ++p)
+            UIG_CHECK_ARG(d.ph_tap0[p + 1] > d.ph_tap0[p], "uig_conv_gather: transposed phase %d has no taps (k=%dx%d s=%d p=%d)", p, kH, kW, stride, pad);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == UIG_BF16 ? dispatch_igemm<bf16_t>(x, wp, bias, y, d, s) : dispatch_igemm<float>(x, wp, bias, y, d, s);
+}

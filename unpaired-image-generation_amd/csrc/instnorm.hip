@@ -1,0 +1,230 @@
+// instnorm.hip — InstanceNorm2d (no affine, biased variance) fused with ReLU / LeakyReLU / residual add, fwd + bwd,
+// and the per-channel column sum used for conv bias gradients.  NHWC, HBM-bound: every lane moves 16-byte chunks
+// (8 bf16 / 4 f32 channels), a thread keeps the same channel chunk for all its pixels, per-thread fp32 partial sums are
+// combined across the block's pixel lanes through LDS, written as per-slab partials and finished in fp64 by a tiny
+// finalize kernel (deterministic: no float atomics).
+//   aten::instance_norm(use_input_stats=True, weight=None)   /   aten::native_batch_norm_backward   
+#include "uig_common.h"
+#include <algorithm>
+
+// MODE 0: (sum x, sum x^2)      MODE 1: (sum g, sum g*xhat) with g = dy * act'(xhat)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                        const float* __restrict__ stats, float* __restrict__ partial,
+                                                        long HW, int C, int CC, int nslab, int act, float slope) {
+    constexpr int E = ElemTraits<T>::E;
+    __shared__ float red[256 * E * 2];
+    const int tid = threadIdx.x;
+    const int PL = 256 / CC, pl = tid / CC, cc = tid % CC;
+    const int b = blockIdx.y, slab = blockIdx.x;
+    const long sp = (HW + nslab - 1) / nslab;
+    const long p0 = slab * sp, p1 = min(HW, p0 + sp);
+    const T* xb = x + (long)b * HW * C + cc * E;
+    float s1[E], s2[E], mu[E], rs[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { s1[e] = 0.f; s2[e] = 0.f; mu[e] = 0.f; rs[e] = 1.f; }
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) { mu[e] = stats[((long)b * C + cc * E + e) * 2]; rs[e] = stats[((long)b * C + cc * E + e) * 2 + 1]; }
+    }
+    const T* dyb = (MODE == 1) ? dy + (long)b * HW * C + cc * E : nullptr;
+    for (long p = p0 + pl; p < p1; p += PL) {
+        float xv[E];
+        chunk_to_f32<T>(*reinterpret_cast<const u32x4_t*>(xb + p * C), xv);
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) { s1[e] += xv[e]; s2[e] += xv[e] * xv[e]; }
+        } else {
+            float gv[E];
+            chunk_to_f32<T>(*reinterpret_cast<const u32x4_t*>(dyb + p * C), gv);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float xh = (xv[e] - mu[e]) * rs[e];
+                float g = gv[e];
+                if (act == UIG_ACT_RELU) g = xh > 0.f ? g : 0.f;
+                else if (act == UIG_ACT_LRELU) g = xh > 0.f ? g : g * slope;
+                s1[e] += g; s2[e] += g * xh;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) { red[(tid * E + e) * 2] = s1[e]; red[(tid * E + e) * 2 + 1] = s2[e]; }
+    __syncthreads();
+    // channel c = cc*E + e lives at red[((pl*CC + cc)*E + e)*2] = red[(pl*C + c)*2]
+    for (int c = tid; c < C; c += 256) {
+        float a = 0.f, q = 0.f;
+        for (int l = 0; l < PL; ++l) { a += red[(l * C + c) * 2]; q += red[(l * C + c) * 2 + 1]; }
+        float* out = partial + (((long)b * nslab + slab) * C + c) * 2;
+        out[0] = a; out[1] = q;
+    }
+}
+
+// fin MODE 0: stats = (mean, rstd)   MODE 1: out = (mean_g, mean_gxhat)   MODE 2: db[c] (+)= sum (B folded into slabs)
+__global__ void in_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, int BC, int C, int nslab,
+                                   double inv_n, float eps, int mode, int nreal, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BC) return;
+    const int b = i / C, c = i % C;
+    double a = 0.0, q = 0.0;
+    for (int s = 0; s < nslab; ++s) {
+        const float* p = partial + (((long)b * nslab + s) * C + c) * 2;
+        a += (double)p[0]; q += (double)p[1];
+    }
+    if (mode == 0) {
+        const double mean = a * inv_n;
+        double var = q * inv_n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        out[(long)i * 2] = (float)mean;
+        out[(long)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    } else if (mode == 1) {
+        out[(long)i * 2] = (float)(a * inv_n);
+        out[(long)i * 2 + 1] = (float)(q * inv_n);
+    } else {
+        if (c < nreal) out[c] = accumulate ? out[c] + (float)a : (float)a;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void in_apply_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                            T* __restrict__ y, const float* __restrict__ stats,
+                                                            long HW, int C, int CC, int nslab, int act, float slope) {
+    constexpr int E = ElemTraits<T>::E;
+    const int tid = threadIdx.x;
+    const int PL = 256 / CC, pl = tid / CC, cc = tid % CC;
+    const int b = blockIdx.y;
+    const long sp = (HW + nslab - 1) / nslab;
+    const long p0 = blockIdx.x * sp, p1 = min(HW, p0 + sp);
+    const long base = (long)b * HW * C + cc * E;
+    float mu[E], rs[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { mu[e] = stats[((long)b * C + cc * E + e) * 2]; rs[e] = stats[((long)b * C + cc * E + e) * 2 + 1]; }
+    for (long p = p0 + pl; p < p1; p += PL) {
+        float v[E];
+        chunk_to_f32<T>(*reinterpret_cast<const u32x4_t*>(x + base + p * C), v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = apply_act((v[e] - mu[e]) * rs[e], act, slope);
+        if (res != nullptr) {
+            float r[E];
+            chunk_to_f32<T>(*reinterpret_cast<const u32x4_t*>(res + base + p * C), r);
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] += r[e];
+        }
+        *reinterpret_cast<u32x4_t*>(y + base + p * C) = f32_to_chunk<T>(v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void in_apply_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            T* __restrict__ dx, const float* __restrict__ stats,
+                                                            const float* __restrict__ gm, long HW, int C, int CC,
+                                                            int nslab, int act, float slope) {
+    constexpr int E = ElemTraits<T>::E;
+    const int tid = threadIdx.x;
+    const int PL = 256 / CC, pl = tid / CC, cc = tid % CC;
+    const int b = blockIdx.y;
+    const long sp = (HW + nslab - 1) / nslab;
+    const long p0 = blockIdx.x * sp, p1 = min(HW, p0 + sp);
+    const long base = (long)b * HW * C + cc * E;
+    float mu[E], rs[E], mg[E], mgx[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const long i = ((long)b * C + cc * E + e) * 2;
+        mu[e] = stats[i]; rs[e] = stats[i + 1]; mg[e] = gm[i]; mgx[e] = gm[i + 1];
+    }
+    for (long p = p0 + pl; p < p1; p += PL) {
+        float xv[E], gv[E];
+        chunk_to_f32<T>(*reinterpret_cast<const u32x4_t*>(x + base + p * C), xv);
+        chunk_to_f32<T>(*reinterpret_cast<const u32x4_t*>(dy + base + p * C), gv);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const float xh = (xv[e] - mu[e]) * rs[e];
+            float g = gv[e];
+            if (act == UIG_ACT_RELU) g = xh > 0.f ? g : 0.f;
+            else if (act == UIG_ACT_LRELU) g = xh > 0.f ? g : g * slope;
+            gv[e] = rs[e] * (g - mg[e] - xh * mgx[e]);
+        }
+        *reinterpret_cast<u32x4_t*>(dx + base + p * C) = f32_to_chunk<T>(gv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static int stats_slabs(long HW, int CC) { return (int)std::max<long>(1, std::min<long>(128, HW * CC / (256 * 8))); }
+static int apply_slabs(long HW, int CC) { return (int)std::max<long>(1, std::min<long>(2048, HW * CC / (256 * 4))); }
+
+static int check_in_args(const char* fn, int B, long HW, int C, int dtype, int* CC) {
+    UIG_CHECK_ARG(dtype == UIG_F32 || dtype == UIG_BF16, "%s: bad dtype %d", fn, dtype);
+    const int E = dtype == UIG_BF16 ? 8 : 4;
+    UIG_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C % E == 0, "%s: bad shape B=%d HW=%ld C=%d", fn, B, HW, C);
+    *CC = C / E;
+    UIG_CHECK_ARG(*CC <= 256 && (256 % *CC) == 0, "%s: C=%d unsupported (C/%d must divide 256)", fn, C, E);
+    UIG_CHECK_ARG(B <= 65535, "%s: B too large", fn);
+    return 0;
+}
+
+extern "C" size_t uig_instnorm_workspace_floats(int B, int64_t HW, int C) {
+    (void)HW;
+    return (size_t)B * 128 * C * 2 + (size_t)B * C * 2;
+}
+extern "C" size_t uig_colsum_workspace_floats(int C) { return (size_t)128 * C * 2; }
+
+extern "C" int uig_instnorm_act_fwd(const void* x, const void* residual, void* y, float* stats, float* workspace,
+                                    int B, int64_t HW, int C, float eps, int act, float slope, int dtype, void* stream) {
+    UIG_CHECK_ARG(x && y && stats && workspace, "uig_instnorm_act_fwd: null pointer");
+    UIG_CHECK_ARG(act == UIG_ACT_NONE || act == UIG_ACT_RELU || act == UIG_ACT_LRELU, "uig_instnorm_act_fwd: bad act %d", act);
+    int CC; if (int r = check_in_args("uig_instnorm_act_fwd", B, HW, C, dtype, &CC)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    const int ns = stats_slabs(HW, CC), na = apply_slabs(HW, CC);
+    if (dtype == UIG_BF16)
+        hipLaunchKernelGGL((in_stats_kernel<bf16_t, 0>), dim3(ns, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, workspace, (long)HW, C, CC, ns, 0, 0.f);
+    else
+        hipLaunchKernelGGL((in_stats_kernel<float, 0>), dim3(ns, B), dim3(256), 0, s, (const float*)x, (const float*)nullptr, (const float*)nullptr, workspace, (long)HW, C, CC, ns, 0, 0.f);
+    UIG_LAUNCH_CHECK("uig_instnorm_act_fwd(stats)");
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, workspace, stats, B * C, C, ns, 1.0 / (double)HW, eps, 0, 0, 0);
+    UIG_LAUNCH_CHECK("uig_instnorm_act_fwd(finalize)");
+    if (dtype == UIG_BF16)
+        hipLaunchKernelGGL((in_apply_fwd_kernel<bf16_t>), dim3(na, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, stats, (long)HW, C, CC, na, act, slope);
+    else
+        hipLaunchKernelGGL((in_apply_fwd_kernel<float>), dim3(na, B), dim3(256), 0, s, (const float*)x, (const float*)residual, (float*)y, stats, (long)HW, C, CC, na, act, slope);
+    UIG_LAUNCH_CHECK("uig_instnorm_act_fwd(apply)");
+    return 0;
+}
+
+extern "C" int uig_instnorm_act_bwd(const void* dy, const void* x, const float* stats, void* dx, float* workspace,
+                                    int B, int64_t HW, int C, int act, float slope, int dtype, void* stream) {
+    UIG_CHECK_ARG(dy && x && stats && dx && workspace, "uig_instnorm_act_bwd: null pointer");
+    UIG_CHECK_ARG(act == UIG_ACT_NONE || act == UIG_ACT_RELU || act == UIG_ACT_LRELU, "uig_instnorm_act_bwd: bad act %d", act);
+    int CC; if (int r = check_in_args("uig_instnorm_act_bwd", B, HW, C, dtype, &CC)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    const int ns = stats_slabs(HW, CC), na = apply_slabs(HW, CC);
+    float* gm = workspace + (size_t)B * 128 * C * 2;
+    if (dtype == UIG_BF16)
+        hipLaunchKernelGGL((in_stats_kernel<bf16_t, 1>), dim3(ns, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, stats, workspace, (long)HW, C, CC, ns, act, slope);
+    else
+        hipLaunchKernelGGL((in_stats_kernel<float, 1>), dim3(ns, B), dim3(256), 0, s, (const float*)x, (const float*)dy, stats, workspace, (long)HW, C, CC, ns, act, slope);
+    UIG_LAUNCH_CHECK("uig_instnorm_act_bwd(stats)");
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, workspace, gm, B * C, C, ns, 1.0 / (double)HW, 0.f, 1, 0, 0);
+    UIG_LAUNCH_CHECK("uig_instnorm_act_bwd(finalize)");
+    if (dtype == UIG_BF16)
+        hipLaunchKernelGGL((in_apply_bwd_kernel<bf16_t>), dim3(na, B), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, stats, gm, (long)HW, C, CC, na, act, slope);
+    else
+        hipLaunchKernelGGL((in_apply_bwd_kernel<float>), dim3(na, B), dim3(256), 0, s, (const float*)dy, (const float*)x, (float*)dx, stats, gm, (long)HW, C, CC, na, act, slope);
+    UIG_LAUNCH_CHECK("uig_instnorm_act_bwd(apply)");
+    return 0;
+}
+
+extern "C" int uig_bias_grad(const void* dy, float* db, float* workspace, int64_t pixels, int C, int Nreal,
+                             int accumulate, int dtype, void* stream) {
+    UIG_CHECK_ARG(dy && db && workspace, "uig_bias_grad: null pointer");
+    UIG_CHECK_ARG(Nreal > 0 && Nreal <= C, "uig_bias_grad: bad Nreal=%d C=%d", Nreal, C);
+    int CC; if (int r = check_in_args("uig_bias_grad", 1, pixels, C, dtype, &CC)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    const int ns = stats_slabs(pixels, CC);
+    if (dtype == UIG_BF16)
+        hipLaunchKernelGGL((in_stats_kernel<bf16_t, 0>), dim3(ns, 1), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)nullptr, (const float*)nullptr, workspace, (long)pixels, C, CC, ns, 0, 0.f);
+    else
+        hipLaunchKernelGGL((in_stats_kernel<float, 0>), dim3(ns, 1), dim3(256), 0, s, (const float*)dy, (const float*)nullptr, (const float*)nullptr, workspace, (long)pixels, C, CC, ns, 0, 0.f);
+    UIG_LAUNCH_CHECK("uig_bias_grad(partial)");
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, workspace, db, C, C, ns, 1.0, 0.f, 2, Nreal, accumulate);
+    UIG_LAUNCH_CHECK("uig_bias_grad(finalize)");
+    return 0;
+}

@@ -1,0 +1,79 @@
+// uig_common.h — shared device helpers for the gfx950 kernels (wave64, MFMA 16x16, LDS tiles of 128-byte rows).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/uig.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+struct bf16_t { unsigned short v; };   // storage-only bf16
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+// round-to-nearest-even; NaN stays NaN (compiler emits v_cvt_pk_bf16_f32 for the __bf16 cast on gfx950)
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+    static constexpr int E = 4;   // elements per 16-byte chunk
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct ElemTraits<bf16_t> {
+    static constexpr int E = 8;
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(p->v); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { p->v = f32_to_bf16(v); }
+};
+
+// 16-byte chunk <-> E floats
+template <typename T> __device__ __forceinline__ void chunk_to_f32(const u32x4_t& c, float* f);
+template <> __device__ __forceinline__ void chunk_to_f32<float>(const u32x4_t& c, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(c[i]);
+}
+template <> __device__ __forceinline__ void chunk_to_f32<bf16_t>(const u32x4_t& c, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(c[i] << 16); f[2 * i + 1] = __uint_as_float(c[i] & 0xffff0000u); }
+}
+template <typename T> __device__ __forceinline__ u32x4_t f32_to_chunk(const float* f);
+template <> __device__ __forceinline__ u32x4_t f32_to_chunk<float>(const float* f) {
+    u32x4_t c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = __float_as_uint(f[i]);
+    return c;
+}
+template <> __device__ __forceinline__ u32x4_t f32_to_chunk<bf16_t>(const float* f) {
+    u32x4_t c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = (unsigned)f32_to_bf16(f[2 * i]) | ((unsigned)f32_to_bf16(f[2 * i + 1]) << 16);
+    return c;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+    switch (act) {
+        case UIG_ACT_RELU: return v > 0.f ? v : 0.f;
+        case UIG_ACT_LRELU: return v > 0.f ? v : v * slope;
+        case UIG_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// wave64 all-reduce sum via DPP-free shuffles (width 64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// host-side error plumbing (defined in uig_capi.hip)
+int uig_set_error(int code, const char* fmt, ...);
+#define UIG_CHECK_ARG(cond, ...) do { if (!(cond)) return uig_set_error(-1, __VA_ARGS__); } while (0)
+#define UIG_LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return uig_set_error((int)e_, "%s: launch failed: %s", name, hipGetErrorString(e_)); } while (0)

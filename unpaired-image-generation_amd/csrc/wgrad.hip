@@ -1,0 +1,259 @@
+// wgrad.hip — weight-gradient GEMM (aten::convolution_backward, weight grad) for gfx950.
+//
+//   part[s][n][col] = sum_{pixels m in split s} P[m][n] * Q[pix(m, tap(col))][c(col)],   col = tap*Cq + c
+//
+// The reduction runs over PIXELS, which is the slow (strided) index of both NHWC operands, so both MFMA operands are
+// "transposed" reads: tiles are staged as [pixel][channel] rows in LDS (coalesced 16-byte chunks from HBM) and
+//   bf16: fragments come from ds_read_b64_tr_b16 (hardware transpose read, 4 pixel rows x 16 channels per 16 lanes)
+//   f32 : v_mfma_f32_16x16x4_f32 takes one value per lane, read with conflict-free ds_read_b32.
+// Output tiles are few (e.g. 2 x 18 for a 256->256 3x3), so the pixel range is split over gridDim.y and the fp32
+// partial slabs are summed by wgrad_reduce_kernel (deterministic; no float atomics), which also transposes
+// [n][tap][c] -> torch's [d0][d1][kH][kW] and drops the padded channels.
+#include "uig_common.h"
+
+struct WgradDesc {
+    int B, Mh, Mw, Np;       // dense operand P: (B, Mh, Mw, Np)
+    int Hq, Wq, Cq;          // gathered operand Q: (B, Hq, Wq, Cq)
+    int kW, taps, stride, pad, pad_mode;
+    int ncols;               // taps * Cq
+    int M, Mper;             // pixels total, pixels per split (multiple of 32)
+};
+
+template <typename T> struct WgTraits;
+template <> struct WgTraits<bf16_t> { static constexpr int PAD = 32; };
+template <> struct WgTraits<float> { static constexpr int PAD = 64; };
+
+template <typename T, int BN>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const T* __restrict__ P, const T* __restrict__ Q,
+                                                        float* __restrict__ part, const WgradDesc d) {
+    constexpr int E = ElemTraits<T>::E;
+    constexpr int BC = 128, BKP = 32;
+    constexpr int WAVES_N = (BN >= 128) ? 2 : 1, WAVES_C = 4 / WAVES_N;
+    constexpr int WN = BN / WAVES_N, WC = BC / WAVES_C, NT = WN / 16, CT = WC / 16;
+    constexpr int PROW = BN * (int)sizeof(T) + WgTraits<T>::PAD;      // LDS row strides (bytes)
+    constexpr int QROW = BC * (int)sizeof(T) + WgTraits<T>::PAD;
+    constexpr int STAGE = BKP * (PROW + QROW);
+    constexpr int PCH = BN / E, QCH = BC / E;                          // 16-byte chunks per row
+    constexpr int PI = (BKP * PCH + 255) / 256, QI = (BKP * QCH + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntn = (d.Np + BN - 1) / BN;
+    const int n_base = (blockIdx.x % ntn) * BN, col_base = (blockIdx.x / ntn) * BC;
+    const int m_begin = blockIdx.y * d.Mper;
+    const int m_end = min(d.M, m_begin + d.Mper);
+    const int nk = (m_end > m_begin) ? (m_end - m_begin + BKP - 1) / BKP : 0;
+
+    // fixed per-thread chunk columns
+    int q_c[QI], q_dh[QI], q_dw[QI], q_row[QI]; bool q_ok[QI];
+#pragma unroll
+    for (int i = 0; i < QI; ++i) {
+        const int id = tid + 256 * i;
+        q_row[i] = id / QCH;
+        const int col = col_base + (id % QCH) * E;
+        q_ok[i] = (id < BKP * QCH) && (col < d.ncols);
+        const int tap = q_ok[i] ? col / d.Cq : 0;
+        q_c[i] = q_ok[i] ? col % d.Cq : 0;
+        q_dh[i] = tap / d.kW - d.pad; q_dw[i] = tap % d.kW - d.pad;
+    }
+    int p_n[PI], p_row[PI]; bool p_ok[PI];
+#pragma unroll
+    for (int i = 0; i < PI; ++i) {
+        const int id = tid + 256 * i;
+        p_row[i] = id / PCH;
+        p_n[i] = n_base + (id % PCH) * E;
+        p_ok[i] = (id < BKP * PCH) && (p_n[i] < d.Np);
+    }
+
+    u32x4_t rq[QI], rp[PI];
+    auto load_tile = [&](int ks) {
+        const int mk = m_begin + ks * BKP;
+#pragma unroll
+        for (int i = 0; i < QI; ++i) {
+            const int m = mk + q_row[i];
+            bool ok = q_ok[i] && (m < m_end);
+            const int mm = ok ? m : 0;
+            const int jj = mm % d.Mw, t = mm / d.Mw, ii = t % d.Mh, b = t / d.Mh;
+            int hi = ii * d.stride + q_dh[i], wi = jj * d.stride + q_dw[i];
+            if (d.pad_mode == UIG_PAD_REFLECT) { hi = reflect_idx(hi, d.Hq); wi = reflect_idx(wi, d.Wq); }
+            else ok = ok && ((unsigned)hi < (unsigned)d.Hq) && ((unsigned)wi < (unsigned)d.Wq);
+            const long off = ((long)((b * d.Hq + hi) * d.Wq + wi)) * d.Cq + q_c[i];
+            u32x4_t z = {0u, 0u, 0u, 0u};
+            rq[i] = ok ? *reinterpret_cast<const u32x4_t*>(Q + off) : z;
+        }
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            const int m = mk + p_row[i];
+            const bool ok = p_ok[i] && (m < m_end);
+            u32x4_t z = {0u, 0u, 0u, 0u};
+            rp[i] = ok ? *reinterpret_cast<const u32x4_t*>(P + (long)m * d.Np + p_n[i]) : z;
+        }
+    };
+    auto store_tile = [&](int stage) {
+        unsigned char* sp = smem + stage * STAGE;
+        unsigned char* sq = sp + BKP * PROW;
+#pragma unroll
+        for (int i = 0; i < QI; ++i) {
+            const int id = tid + 256 * i;
+            if (id < BKP * QCH) *reinterpret_cast<u32x4_t*>(sq + q_row[i] * QROW + (id % QCH) * 16) = rq[i];
+        }
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            const int id = tid + 256 * i;
+            if (id < BKP * PCH) *reinterpret_cast<u32x4_t*>(sp + p_row[i] * PROW + (id % PCH) * 16) = rp[i];
+        }
+    };
+
+    f32x4_t acc[CT][NT];
+#pragma unroll
+    for (int a = 0; a < CT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int wn = wave % WAVES_N, wc = wave / WAVES_N;
+    const int l16 = lane & 15, g = lane >> 4;
+
+    if (nk > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < nk) load_tile(ks + 1);
+        const unsigned char* sp = smem + cur * STAGE;
+        const unsigned char* sq = sp + BKP * PROW;
+        if constexpr (sizeof(T) == 2) {
+            // bf16: transpose reads. lane 4q+p of a 16-lane group addresses pixel row (4g+q [+16]), channels 4p..4p+3;
+            // it receives channel l16 of those 4 pixel rows. fragment k order: {4g..4g+3, 16+4g..16+4g+3} for both operands.
+            const int qq = l16 >> 2, pp = l16 & 3;
+            bf16x8_t af[CT], bf[NT];
+#pragma unroll
+            for (int a = 0; a < CT; ++a) {
+                const unsigned char* base = sq + (4 * g + qq) * QROW + (wc * WC + a * 16 + 4 * pp) * 2;
+                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(base));
+                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(base + 16 * QROW));
+                af[a] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const unsigned char* base = sp + (4 * g + qq) * PROW + (wn * WN + b * 16 + 4 * pp) * 2;
+                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(base));
+                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(base + 16 * PROW));
+                bf[b] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int a = 0; a < CT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        } else {
+            // f32: A[i = l16][k = g] per 16x16x4 step; pixel row = 4*kk + g
+#pragma unroll
+            for (int kk = 0; kk < BKP / 4; ++kk) {
+                float af[CT], bf[NT];
+#pragma unroll
+                for (int a = 0; a < CT; ++a)
+                    af[a] = *reinterpret_cast<const float*>(sq + (4 * kk + g) * QROW + (wc * WC + a * 16 + l16) * 4);
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    bf[b] = *reinterpret_cast<const float*>(sp + (4 * kk + g) * PROW + (wn * WN + b * 16 + l16) * 4);
+#pragma unroll
+                for (int a = 0; a < CT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+            }
+        }
+        if (ks + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // D[col][n]: lane holds n = l16 (B-operand column), cols 4g..4g+3 (rows) -> one float4 per tile into part[s][n][col]
+    float* out = part + (long)blockIdx.y * d.Np * d.ncols;
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int n = n_base + wn * WN + b * 16 + l16;
+        if (n >= d.Np) continue;
+#pragma unroll
+        for (int a = 0; a < CT; ++a) {
+            const int col = col_base + wc * WC + a * 16 + 4 * g;
+            if (col >= d.ncols) continue;     // ncols is a multiple of 8, col of 4: a chunk is fully in or out
+            *reinterpret_cast<f32x4_t*>(out + (long)n * d.ncols + col) = acc[a][b];
+        }
+    }
+}
+
+// dW[d0][d1][tap] (+)= sum_s part[s][d0][tap][d1]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int Np, int Cq, int taps,
+                                    int splits, int D0, int D1, int accumulate) {
+    const long total = (long)D0 * D1 * taps;
+    const long slab = (long)Np * taps * Cq;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        // iterate in the INPUT order (d0, tap, d1) so reads are coalesced; writes are a small strided transpose
+        const int d1 = (int)(i % D1); const long r = i / D1; const int tap = (int)(r % taps); const int d0 = (int)(r / taps);
+        const long src = ((long)d0 * taps + tap) * Cq + d1;
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += part[k * slab + src];
+        const long dst = ((long)d0 * D1 + d1) * taps + tap;
+        dW[dst] = accumulate ? dW[dst] + s : s;
+    }
+}
+
+extern "C" size_t uig_wgrad_workspace_bytes(int Np, int Cq, int kH, int kW, int splits) {
+    return (size_t)splits * Np * kH * kW * Cq * sizeof(float);
+}
+
+template <typename T, int BN>
+static int launch_wgrad(const void* P, const void* Q, float* ws, const WgradDesc& d, int splits, hipStream_t s) {
+    constexpr int PROW = BN * (int)sizeof(T) + WgTraits<T>::PAD, QROW = 128 * (int)sizeof(T) + WgTraits<T>::PAD;
+    const size_t smem = 2 * 32 * (size_t)(PROW + QROW);
+    auto kern = wgrad_kernel<T, BN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return uig_set_error((int)e, "wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    const int ntn = (d.Np + BN - 1) / BN, ntc = (d.ncols + 127) / 128;
+    hipLaunchKernelGGL(kern, dim3(ntn * ntc, splits), dim3(256), smem, s, (const T*)P, (const T*)Q, ws, d);
+    UIG_LAUNCH_CHECK("uig_wgrad_partial");
+    return 0;
+}
+
+extern "C" int uig_wgrad_partial(const void* P, const void* Q, float* workspace, int B, int Mh, int Mw, int Np,
+                                 int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int pad_mode,
+                                 int splits, int dtype, void* stream) {
+    UIG_CHECK_ARG(P && Q && workspace, "uig_wgrad_partial: null pointer");
+    UIG_CHECK_ARG(Np % 8 == 0 && Cq % 8 == 0 && Np > 0 && Cq > 0, "uig_wgrad_partial: channels must be padded to 8 (Np=%d Cq=%d)", Np, Cq);
+    UIG_CHECK_ARG(splits >= 1 && splits <= 65535, "uig_wgrad_partial: bad splits %d", splits);
+    UIG_CHECK_ARG(stride == 1 || stride == 2, "uig_wgrad_partial: stride=%d unsupported", stride);
+    UIG_CHECK_ARG(dtype == UIG_F32 || dtype == UIG_BF16, "uig_wgrad_partial: bad dtype %d", dtype);
+    UIG_CHECK_ARG((long)B * Mh * Mw * Np < (1L << 31) && (long)B * Hq * Wq * Cq < (1L << 31), "uig_wgrad_partial: tensor too large");
+    if (pad_mode == UIG_PAD_REFLECT) {
+        UIG_CHECK_ARG(pad < Hq && pad < Wq, "uig_wgrad_partial: reflect pad %d >= dim", pad);
+    }
+    // every gathered coordinate must be reachable: (Mh-1)*stride + kH-1 - pad <= Hq-1 + pad
+    UIG_CHECK_ARG((Mh - 1) * stride + kH - 1 - pad <= Hq - 1 + pad && (Mw - 1) * stride + kW - 1 - pad <= Wq - 1 + pad,
+                  "uig_wgrad_partial: gather window exceeds the padded input (Mh=%d Hq=%d k=%d s=%d p=%d)", Mh, Hq, kH, stride, pad);
+    WgradDesc d{};
+    d.B = B; d.Mh = Mh; d.Mw = Mw; d.Np = Np; d.Hq = Hq; d.Wq = Wq; d.Cq = Cq;
+    d.kW = kW; d.taps = kH * kW; d.stride = stride; d.pad = pad; d.pad_mode = pad_mode;
+    d.ncols = kH * kW * Cq; d.M = B * Mh * Mw;
+    d.Mper = ((d.M + splits - 1) / splits + 31) / 32 * 32;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UIG_BF16)
+        return Np <= 16 ? launch_wgrad<bf16_t, 16>(P, Q, workspace, d, splits, s) : launch_wgrad<bf16_t, 128>(P, Q, workspace, d, splits, s);
+    return Np <= 16 ? launch_wgrad<float, 16>(P, Q, workspace, d, splits, s) : launch_wgrad<float, 128>(P, Q, workspace, d, splits, s);
+}
+
+extern "C" int uig_wgrad_reduce(const float* workspace, float* dW, int Np, int Cq, int taps, int splits,
+                                int D0, int D1, int accumulate, void* stream) {
+    UIG_CHECK_ARG(workspace && dW, "uig_wgrad_reduce: null pointer");
+    UIG_CHECK_ARG(D0 <= Np && D1 <= Cq && D0 > 0 && D1 > 0 && taps > 0 && splits > 0, "uig_wgrad_reduce: bad dims");
+    const long total = (long)D0 * D1 * taps;
+    const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate);
+    UIG_LAUNCH_CHECK("uig_wgrad_reduce");
+    return 0;
+}

@@ -1,0 +1,197 @@
+"""CycleGAN train step (layer L4) on the HIP operator path, single GPU or data parallel.
+
+`CycleGAN.train_step(real_A, real_B)` performs exactly the canonical optimisation step:
+  fake_B=G_A(A) rec_A=G_B(fake_B) fake_A=G_B(B) rec_B=G_A(fake_A) idt_A=G_A(B) idt_B=G_B(A);
+  loss_G = MSE(D_A(fake_B),1)+MSE(D_B(fake_A),1) + lam*L1(rec_A,A)+lam*L1(rec_B,B) + lam*idt*(L1(idt_A,B)+L1(idt_B,A));
+  Adam(G);  loss_D_X = 0.5*(MSE(D_X(real),1)+MSE(D_X(fake.detach()),0));  Adam(D).
+MI355X-first choices (all result-preserving because InstanceNorm statistics are per sample):
+  * the two passes that share a generator's weights and have no data dependency (fake and identity) run as ONE batch-2B
+    launch sequence (fills the 256 CUs at small per-GPU batch); the discriminators see [real; fake] as one batch;
+  * parameters, gradients and Adam moments of each optimiser group live in ONE flat fp32 buffer: Adam is a single
+    kernel and the data-parallel exchange a single RCCL all-reduce per group;
+  * the whole step is static-shape and sync-free, so it is captured once into HIP graphs and replayed
+    (segments: G fwd+bwd | D fwd+bwd | Adam G | Adam D), with the gradient all-reduces enqueued between segments on a
+    communication stream: the generator all-reduce overlaps the discriminators' forward+backward, the discriminator
+    all-reduce overlaps the generator Adam.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .networks import Discriminator, Generator
+
+LOSS_NAMES = ("idt_A", "idt_B", "G_A", "G_B", "cyc_A", "cyc_B", "D_A", "D_B")
+
+
+class FlatGroup:
+    """All parameters of an optimiser group as views into one flat fp32 buffer (+ flat grad / Adam m, v)."""
+
+    def __init__(self, nets, device):
+        self.params = [p for n in nets for p in n.parameters()]
+        sizes = [(p.numel() + 3) // 4 * 4 for p in self.params]        # keep every view 16-byte aligned
+        total = sum(sizes)
+        self.flat = torch.zeros(total, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(total, device=device, dtype=torch.float32)
+        self.m = torch.zeros(total, device=device, dtype=torch.float32)
+        self.v = torch.zeros(total, device=device, dtype=torch.float32)
+        off = 0
+        for p, sz in zip(self.params, sizes):
+            n = p.numel()
+            self.flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + n].view(p.shape)
+            p.grad = self.grad[off:off + n].view(p.shape)
+            off += sz
+        self.step = 0
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def set_requires_grad(self, flag: bool):
+        for p in self.params:
+            p.requires_grad_(flag)
+
+
+class CycleGAN:
+    def __init__(self, n_blocks=9, dtype=torch.bfloat16, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-8,
+                 lambda_cyc=10.0, lambda_idt=0.5, device="cuda", process_group=None, use_graph=False, batch_fused=True):
+        self.device, self.dtype = torch.device(device), dtype
+        kw = dict(dtype=dtype, device=device)
+        self.G_A, self.G_B = Generator(n_blocks=n_blocks, **kw), Generator(n_blocks=n_blocks, **kw)
+        self.D_A, self.D_B = Discriminator(**kw), Discriminator(**kw)
+        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        self.lam, self.lam_idt = lambda_cyc, lambda_idt
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
+        self.use_graph, self.batch_fused = use_graph, batch_fused
+        self._graphs = None
+        self._comm_stream = None
+        self._finalize_params()
+
+    # ------------------------------------------------------------------ parameters
+    def nets(self):
+        return (self.G_A, self.G_B, self.D_A, self.D_B)
+
+    def _finalize_params(self):
+        self.grp_G = FlatGroup((self.G_A, self.G_B), self.device)
+        self.grp_D = FlatGroup((self.D_A, self.D_B), self.device)
+        self.repack()
+
+    def load_state_dicts(self, sd_GA, sd_GB, sd_DA, sd_DB):
+        """Load torch-layout fp32 weights (e.g. from the stock-torch modules) into the flat buffers."""
+        with torch.no_grad():
+            for net, sd in zip(self.nets(), (sd_GA, sd_GB, sd_DA, sd_DB)):
+                own = dict(net.named_parameters())
+                if set(own) != set(sd):
+                    raise KeyError(f"state_dict keys differ: {sorted(set(own) ^ set(sd))[:6]}")
+                for k, v in sd.items():
+                    own[k].copy_(v.to(self.device, torch.float32))
+        self.repack()
+
+    def repack(self):
+        for n in self.nets():
+            n.repack()
+
+    def broadcast_params(self, src=0):
+        if self.world > 1:
+            dist.broadcast(self.grp_G.flat, src, group=self.pg)
+            dist.broadcast(self.grp_D.flat, src, group=self.pg)
+            self.repack()
+
+    # ------------------------------------------------------------------ step pieces (all async, static shapes)
+    def _g_phase(self, xa, xb):
+        """generator forward (6 passes) + D forward (frozen) + 6 losses + backward -> grads in grp_G.grad"""
+        B = xa.shape[0]
+        self.grp_D.set_requires_grad(False)
+        self.grp_G.zero_grad()
+        if self.batch_fused:
+            oa = self.G_A.forward_phys(torch.cat([xa, xb]))      # [fake_B ; idt_A]
+            ob = self.G_B.forward_phys(torch.cat([xb, xa]))      # [fake_A ; idt_B]
+            fake_B, idt_A, fake_A, idt_B = oa[:B], oa[B:], ob[:B], ob[B:]
+        else:
+            fake_B, fake_A = self.G_A.forward_phys(xa), self.G_B.forward_phys(xb)
+            idt_A, idt_B = self.G_A.forward_phys(xb), self.G_B.forward_phys(xa)
+        rec_A = self.G_B.forward_phys(fake_B)
+        rec_B = self.G_A.forward_phys(fake_A)
+        n_real = B * xa.shape[1] * xa.shape[2] * 3
+        l_idt_A = ops.l1_loss(idt_A, xb, self.lam * self.lam_idt, n_real)
+        l_idt_B = ops.l1_loss(idt_B, xa, self.lam * self.lam_idt, n_real)
+        l_G_A = ops.mse_const(self.D_A.forward_phys(fake_B), 1.0)
+        l_G_B = ops.mse_const(self.D_B.forward_phys(fake_A), 1.0)
+        l_cyc_A = ops.l1_loss(rec_A, xa, self.lam, n_real)
+        l_cyc_B = ops.l1_loss(rec_B, xb, self.lam, n_real)
+        losses = [l_idt_A, l_idt_B, l_G_A, l_G_B, l_cyc_A, l_cyc_B]
+        torch.autograd.backward(losses)
+        self.grp_D.set_requires_grad(True)
+        self.last_fake_B = fake_B.detach()
+        return fake_B.detach(), fake_A.detach(), losses
+
+    def _d_phase(self, xa, xb, fake_B, fake_A):
+        self.grp_D.zero_grad()
+        B = xa.shape[0]
+        out = []
+        for D, real, fake in ((self.D_A, xb, fake_B), (self.D_B, xa, fake_A)):
+            if self.batch_fused:
+                p = D.forward_phys(torch.cat([real, fake]))
+                l_real, l_fake = ops.mse_const(p[:B], 1.0, 0.5), ops.mse_const(p[B:], 0.0, 0.5)
+            else:
+                l_real, l_fake = ops.mse_const(D.forward_phys(real), 1.0, 0.5), ops.mse_const(D.forward_phys(fake), 0.0, 0.5)
+            torch.autograd.backward([l_real, l_fake])
+            out.append((l_real, l_fake))
+        return out
+
+    def _adam(self, grp):
+        grp.step += 1
+        ops.adam_flat(grp.flat, grp.grad, grp.m, grp.v, self.lr, self.b1, self.b2, self.eps, grp.step, 1.0 / self.world)
+
+    def _allreduce(self, grp):
+        """sum-all-reduce of one flat gradient buffer on the communication stream (RCCL over xGMI)."""
+        if self.world <= 1:
+            return None
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=self.device)
+        cur = torch.cuda.current_stream()
+        self._comm_stream.wait_stream(cur)
+        with torch.cuda.stream(self._comm_stream):
+            dist.all_reduce(grp.grad, op=dist.ReduceOp.SUM, group=self.pg)
+        ev = torch.cuda.Event()
+        ev.record(self._comm_stream)
+        return ev
+
+    # ------------------------------------------------------------------ the step
+    def _step_eager(self, xa, xb):
+        self.repack()
+        fake_B, fake_A, lg = self._g_phase(xa, xb)
+        ev_g = self._allreduce(self.grp_G)               # overlaps the whole discriminator phase
+        ld = self._d_phase(xa, xb, fake_B, fake_A)
+        if ev_g is not None:
+            torch.cuda.current_stream().wait_event(ev_g)
+        ev_d = self._allreduce(self.grp_D)               # overlaps the generator Adam
+        self._adam(self.grp_G)
+        if ev_d is not None:
+            torch.cuda.current_stream().wait_event(ev_d)
+        self._adam(self.grp_D)
+        l_D_A = ld[0][0] + ld[0][1]
+        l_D_B = ld[1][0] + ld[1][1]
+        return torch.cat(lg + [l_D_A, l_D_B])
+
+    def to_phys(self, x):
+        return ops.to_nhwc(x, self.dtype)
+
+    def train_step(self, real_A: torch.Tensor, real_B: torch.Tensor, sync: bool = True):
+        """One optimisation step. real_*: logical (B,3,H,W). Returns the 8 losses (dict of floats, or a device tensor
+        of shape (8,) in LOSS_NAMES order when sync=False)."""
+        if self.use_graph:
+            from .graph_step import graph_train_step
+            losses = graph_train_step(self, real_A, real_B)
+        else:
+            losses = self._step_eager(self.to_phys(real_A), self.to_phys(real_B))
+        self.last_losses = losses
+        if not sync:
+            return losses
+        if self.world > 1:
+            losses = losses.clone()
+            dist.all_reduce(losses, op=dist.ReduceOp.SUM, group=self.pg)
+            losses /= self.world
+        return dict(zip(LOSS_NAMES, losses.tolist()))

@@ -1,0 +1,65 @@
+"""ctypes binding of libuig.so (the C ABI declared in include/uig.h).  Fails loudly when the library is missing:
+there is no CPU / PyTorch fallback for any op on the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuig.so")
+_lib = None
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+PAD_ZERO, PAD_REFLECT = 0, 1
+GATHER_DIRECT, GATHER_TRANSPOSED = 0, 1
+PACK_ROW_DIM0, PACK_ROW_DIM1 = 0, 1
+
+_vp, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/uig.h declares (tests/test_abi.py checks this)
+SIGNATURES = {
+    "uig_version": (C.c_char_p, []),
+    "uig_last_error": (C.c_char_p, []),
+    "uig_device_ok": (_i, []),
+    "uig_conv_gather": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_i, _f, _i, _vp]),
+    "uig_wgrad_workspace_bytes": (_sz, [_i] * 5),
+    "uig_wgrad_partial": (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp]),
+    "uig_wgrad_reduce": (_i, [_vp, _vp] + [_i] * 7 + [_vp]),
+    "uig_colsum_workspace_floats": (_sz, [_i]),
+    "uig_bias_grad": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "uig_pack_weight": (_i, [_vp, _vp] + [_i] * 9 + [_vp]),
+    "uig_instnorm_workspace_floats": (_sz, [_i, _i64, _i]),
+    "uig_instnorm_act_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _i, _f, _i, _vp]),
+    "uig_instnorm_act_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _vp]),
+    "uig_reflect_fold": (_i, [_vp, _vp] + [_i] * 6 + [_vp]),
+    "uig_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _f, _i, _vp]),
+    "uig_l1_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f, _i, _vp]),
+    "uig_mse_const_fwd_bwd": (_i, [_vp, _f, _vp, _vp, _vp, _i64, _f, _i, _vp]),
+    "uig_loss_workspace_floats": (_sz, []),
+    "uig_scale_by_scalar": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
+    "uig_adam_flat": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp]),
+    "uig_adam_flat_graph": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _vp, _f, _vp]),
+    "uig_to_nhwc": (_i, [_vp, _i, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "uig_from_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i64, _i64, _i64, _i64, _vp]),
+}
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"libuig.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C unpaired-image-generation_amd/csrc`). There is no fallback path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (status {rc}): {lib().uig_last_error().decode(errors='replace')}")

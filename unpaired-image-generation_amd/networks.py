@@ -1,0 +1,152 @@
+"""Generator / Discriminator modules (layer L3).
+
+Same constructor surface and the same `state_dict` keys as the stock-torch restatement of the architecture
+(`nn.Sequential` indices: '1.weight', '10.b.1.weight', ...): reflection pads, ReLU/LeakyReLU/Tanh are fused into the
+neighbouring HIP kernels, and parameter-free `_Slot` placeholders keep the indices of the modules they replace.
+`forward(x)` takes / returns ordinary logical (B,3,H,W) tensors; `forward_phys` works on the internal NHWC tensors.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from . import ops
+
+
+class _Slot(nn.Module):
+    """Parameter-free placeholder for a module whose work is fused into a neighbouring kernel."""
+
+    def __init__(self, what: str):
+        super().__init__()
+        self.what = what
+
+    def forward(self, x):
+        return x
+
+    def extra_repr(self):
+        return f"fused: {self.what}"
+
+
+class ConvLayer(nn.Module):
+    """Conv2d / ConvTranspose2d (+ fused reflection pad, bias, epilogue activation) on the HIP implicit-GEMM kernel.
+    Parameters keep torch's layouts (fp32 master copy); `repack()` refreshes the kernel-side operands."""
+
+    def __init__(self, kind, cin, cout, k, stride=1, pad=0, pad_mode="zero", act=L.ACT_NONE, slope=0.0,
+                 dtype=torch.bfloat16, device="cuda"):
+        super().__init__()
+        self.spec = ops.ConvSpec(kind, cin, cout, k, stride, pad, pad_mode, act, slope)
+        self.compute_dtype = dtype
+        self.weight = nn.Parameter(torch.empty(self.spec.weight_shape(), device=device, dtype=torch.float32))
+        self.bias = nn.Parameter(torch.zeros(cout, device=device, dtype=torch.float32))
+        nn.init.normal_(self.weight, 0.0, 0.02)
+        sf, sd = ops.packed_shapes(self.spec)
+        # non-persistent: derived data, not part of the state_dict
+        self.register_buffer("wp_fwd", torch.zeros(sf, device=device, dtype=dtype), persistent=False)
+        self.register_buffer("wp_dgrad", torch.zeros(sd, device=device, dtype=dtype), persistent=False)
+        self._packed_version = None
+
+    def repack(self):
+        ops.pack_weights(self.spec, self.weight.data, self.compute_dtype, self.wp_fwd, self.wp_dgrad)
+        self._packed_version = self.weight._version
+
+    def forward(self, x):
+        if self._packed_version != self.weight._version:
+            self.repack()
+        return ops.ConvFn.apply(x, self.weight, self.bias, self)
+
+    def extra_repr(self):
+        s = self.spec
+        return f"{s.kind} {s.cin}->{s.cout} k{s.k} s{s.stride} p{s.pad}{'(reflect)' if s.reflect else ''} act={s.act}"
+
+
+class InstNormAct(nn.Module):
+    """InstanceNorm2d(affine=False, eps=1e-5) fused with ReLU / LeakyReLU and an optional residual add."""
+
+    def __init__(self, act=L.ACT_NONE, slope=0.0, eps=1e-5):
+        super().__init__()
+        self.act, self.slope, self.eps = act, slope, eps
+
+    def forward(self, x, residual=None):
+        return ops.InstNormActFn.apply(x, residual, self.act, self.slope, self.eps)
+
+
+class ResBlock(nn.Module):
+    """x + [ReflPad1, Conv3x3, IN, ReLU, ReflPad1, Conv3x3, IN](x); sub-keys b.1.*, b.5.* as in Appendix A."""
+
+    def __init__(self, dim, dtype, device):
+        super().__init__()
+        self.b = nn.Sequential(
+            _Slot("ReflectionPad2d(1) -> conv gather"),
+            ConvLayer("conv", dim, dim, 3, 1, 1, "reflect", dtype=dtype, device=device),
+            InstNormAct(L.ACT_RELU),
+            _Slot("ReLU -> instnorm"),
+            _Slot("ReflectionPad2d(1) -> conv gather"),
+            ConvLayer("conv", dim, dim, 3, 1, 1, "reflect", dtype=dtype, device=device),
+            InstNormAct(L.ACT_NONE),
+        )
+
+    def forward(self, x):
+        h = self.b[2](self.b[1](x))
+        return self.b[6](self.b[5](h), residual=x)
+
+
+class _PhysNet(nn.Sequential):
+    in_ch = 3
+    out_ch = 3
+    compute_dtype = torch.bfloat16
+
+    def forward_phys(self, xp):
+        for m in self:
+            xp = m(xp)
+        return xp
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != self.in_ch:
+            raise ValueError(f"expected (B,{self.in_ch},H,W), got {tuple(x.shape)}")
+        yp = self.forward_phys(ops.ToPhysFn.apply(x, self.compute_dtype))
+        if yp.shape[3] == self.out_ch:           # unpadded head (1-channel patch logits): (B,H,W,1) == (B,1,H,W)
+            return yp.permute(0, 3, 1, 2).float()
+        return ops.FromPhysFn.apply(yp, self.out_ch, x.dtype if x.dtype.is_floating_point else torch.float32)
+
+    def conv_layers(self):
+        return [m for m in self.modules() if isinstance(m, ConvLayer)]
+
+    def repack(self):
+        for m in self.conv_layers():
+            m.repack()
+
+
+class Generator(_PhysNet):
+    """ResNet generator (Appendix A): c7s1-64, d128, d256, n_blocks x R256, u128, u64, c7s1-3 + tanh."""
+
+    def __init__(self, in_ch=3, out_ch=3, ngf=64, n_blocks=9, dtype=torch.bfloat16, device="cuda"):
+        kw = dict(dtype=dtype, device=device)
+        mods = [_Slot("ReflectionPad2d(3) -> conv gather"), ConvLayer("conv", in_ch, ngf, 7, 1, 3, "reflect", **kw),
+                InstNormAct(L.ACT_RELU), _Slot("ReLU -> instnorm"),
+                ConvLayer("conv", ngf, ngf * 2, 3, 2, 1, **kw), InstNormAct(L.ACT_RELU), _Slot("ReLU -> instnorm"),
+                ConvLayer("conv", ngf * 2, ngf * 4, 3, 2, 1, **kw), InstNormAct(L.ACT_RELU), _Slot("ReLU -> instnorm")]
+        mods += [ResBlock(ngf * 4, dtype, device) for _ in range(n_blocks)]
+        mods += [ConvLayer("convT", ngf * 4, ngf * 2, 3, 2, 1, **kw), InstNormAct(L.ACT_RELU), _Slot("ReLU -> instnorm"),
+                 ConvLayer("convT", ngf * 2, ngf, 3, 2, 1, **kw), InstNormAct(L.ACT_RELU), _Slot("ReLU -> instnorm"),
+                 _Slot("ReflectionPad2d(3) -> conv gather"),
+                 ConvLayer("conv", ngf, out_ch, 7, 1, 3, "reflect", act=L.ACT_TANH, **kw), _Slot("Tanh -> conv epilogue")]
+        super().__init__(*mods)
+        self.in_ch, self.out_ch, self.compute_dtype = in_ch, out_ch, dtype
+
+
+class Discriminator(_PhysNet):
+    """70x70 PatchGAN (Appendix A), LSGAN head (no sigmoid)."""
+
+    def __init__(self, in_ch=3, ndf=64, n_layers=3, dtype=torch.bfloat16, device="cuda"):
+        kw = dict(dtype=dtype, device=device)
+        mods = [ConvLayer("conv", in_ch, ndf, 4, 2, 1, act=L.ACT_LRELU, slope=0.2, **kw), _Slot("LeakyReLU -> conv epilogue")]
+        nf = 1
+        for n in range(1, n_layers):
+            nf_prev, nf = nf, min(2 ** n, 8)
+            mods += [ConvLayer("conv", ndf * nf_prev, ndf * nf, 4, 2, 1, **kw), InstNormAct(L.ACT_LRELU, 0.2), _Slot("LeakyReLU -> instnorm")]
+        nf_prev, nf = nf, min(2 ** n_layers, 8)
+        mods += [ConvLayer("conv", ndf * nf_prev, ndf * nf, 4, 1, 1, **kw), InstNormAct(L.ACT_LRELU, 0.2), _Slot("LeakyReLU -> instnorm")]
+        mods += [ConvLayer("conv", ndf * nf, 1, 4, 1, 1, **kw)]
+        super().__init__(*mods)
+        self.in_ch, self.out_ch, self.compute_dtype = in_ch, 1, dtype

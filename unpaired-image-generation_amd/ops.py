@@ -1,0 +1,336 @@
+"""Operator boundary (layer L2): one torch.autograd.Function per op, each a thin host wrapper that
+enqueues hand-written HIP kernels through the C ABI (include/uig.h) on torch's current stream.
+
+Tensors between ops are PHYSICAL NHWC: shape (B, H, W, Cp), contiguous, channels padded to a multiple of 8 with
+zeros (a 1-channel discriminator output stays unpadded).  torch is used for device memory (caching allocator),
+streams and autograd bookkeeping only; every FLOP on these paths runs in libuig.so.  Missing library => RuntimeError.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import lib as L
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return L.F32
+    if t.dtype == torch.bfloat16:
+        return L.BF16
+    raise TypeError(f"unsupported dtype {t.dtype} (float32 or bfloat16)")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk_phys(t: torch.Tensor, name: str) -> None:
+    if not (t.is_cuda and t.dim() == 4 and t.is_contiguous()):
+        raise ValueError(f"{name}: expected a contiguous CUDA tensor (B,H,W,C), got {tuple(t.shape)} on {t.device}")
+
+
+def pad8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+# ----------------------------------------------------------------------------------------- layout plumbing
+def to_nhwc(x: torch.Tensor, dtype: torch.dtype, cp: int | None = None) -> torch.Tensor:
+    """logical (B,C,H,W) tensor with any strides -> physical (B,H,W,Cp) in `dtype`, zero padded."""
+    B, C, H, W = x.shape
+    cp = pad8(C) if cp is None else cp
+    out = torch.empty((B, H, W, cp), device=x.device, dtype=dtype)
+    sb, sc, sh, sw = x.stride()
+    L.check(L.lib().uig_to_nhwc(_p(x), _dt(x), sb, sc, sh, sw, _p(out), B, C, H, W, cp, _dt(out), _stream()), "uig_to_nhwc")
+    return out
+
+
+def from_nhwc(xp: torch.Tensor, C: int, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """physical (B,H,W,Cp) -> contiguous logical (B,C,H,W) in `dtype`."""
+    B, H, W, cp = xp.shape
+    out = torch.empty((B, C, H, W), device=xp.device, dtype=dtype)
+    sb, sc, sh, sw = out.stride()
+    L.check(L.lib().uig_from_nhwc(_p(xp), B, C, H, W, cp, _dt(xp), _p(out), _dt(out), sb, sc, sh, sw, _stream()), "uig_from_nhwc")
+    return out
+
+
+class ToPhysFn(Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.C, ctx.in_dtype = x.shape[1], x.dtype
+        return to_nhwc(x, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return from_nhwc(g.contiguous(), ctx.C, ctx.in_dtype), None
+
+
+class FromPhysFn(Function):
+    @staticmethod
+    def forward(ctx, xp, C, dtype):
+        ctx.cp, ctx.pdtype = xp.shape[3], xp.dtype
+        return from_nhwc(xp, C, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return to_nhwc(g, ctx.pdtype, ctx.cp), None, None
+
+
+# ----------------------------------------------------------------------------------------- convolution
+class ConvSpec:
+    """Static description of one Conv2d / ConvTranspose2d layer (+ fused reflection pad and epilogue activation)."""
+
+    def __init__(self, kind, cin, cout, k, stride=1, pad=0, pad_mode="zero", act=L.ACT_NONE, slope=0.0):
+        assert kind in ("conv", "convT") and pad_mode in ("zero", "reflect")
+        self.kind, self.cin, self.cout, self.k, self.stride, self.pad = kind, cin, cout, k, stride, pad
+        self.reflect = pad_mode == "reflect"
+        self.act, self.slope = act, slope
+        self.cin_p = pad8(cin)
+        self.cout_p = pad8(cout)                       # channel count of dy as the backward kernels need it
+        self.cout_store = 1 if cout == 1 else self.cout_p   # physical channels of the forward output
+        if kind == "convT":
+            assert stride == 2 and pad == 1 and k == 3 and not self.reflect, "convT: k3 s2 p1 output_padding1 only"
+
+    def out_hw(self, H, W):
+        if self.kind == "conv":
+            return (H + 2 * self.pad - self.k) // self.stride + 1, (W + 2 * self.pad - self.k) // self.stride + 1
+        return 2 * H, 2 * W
+
+    def weight_shape(self):
+        return (self.cout, self.cin, self.k, self.k) if self.kind == "conv" else (self.cin, self.cout, self.k, self.k)
+
+
+def pack_weights(spec: ConvSpec, weight: torch.Tensor, dtype: torch.dtype, wp_fwd: torch.Tensor, wp_dgrad: torch.Tensor):
+    """fp32 torch-layout weight -> the two kernel-side operands [rows][tap][cols] (forward and input-gradient)."""
+    lib, s, k = L.lib(), _stream(), spec.k
+    D0, D1 = weight.shape[0], weight.shape[1]
+    dt = L.BF16 if dtype == torch.bfloat16 else L.F32
+    if spec.kind == "conv":      # fwd rows = Cout (dim0), cols = Cin;  dgrad rows = Cin (dim1), cols = Cout
+        L.check(lib.uig_pack_weight(_p(weight), _p(wp_fwd), D0, D1, k, k, L.PACK_ROW_DIM0, 0, spec.cout, spec.cin_p, dt, s), "uig_pack_weight")
+        L.check(lib.uig_pack_weight(_p(weight), _p(wp_dgrad), D0, D1, k, k, L.PACK_ROW_DIM1, 0, spec.cin, spec.cout_p, dt, s), "uig_pack_weight")
+    else:                        # weight (Cin, Cout, k, k): fwd rows = Cout (dim1); dgrad rows = Cin (dim0)
+        L.check(lib.uig_pack_weight(_p(weight), _p(wp_fwd), D0, D1, k, k, L.PACK_ROW_DIM1, 0, spec.cout, spec.cin_p, dt, s), "uig_pack_weight")
+        L.check(lib.uig_pack_weight(_p(weight), _p(wp_dgrad), D0, D1, k, k, L.PACK_ROW_DIM0, 0, spec.cin, spec.cout_p, dt, s), "uig_pack_weight")
+
+
+def packed_shapes(spec: ConvSpec):
+    t = spec.k * spec.k
+    return (spec.cout, t, spec.cin_p), (spec.cin, t, spec.cout_p)
+
+
+def conv_forward(spec: ConvSpec, x: torch.Tensor, wp_fwd: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
+    _chk_phys(x, "conv_forward")
+    B, H, W, C = x.shape
+    if C != spec.cin_p:
+        raise ValueError(f"conv_forward: input has {C} physical channels, layer expects {spec.cin_p}")
+    Ho, Wo = spec.out_hw(H, W)
+    y = torch.empty((B, Ho, Wo, spec.cout_store), device=x.device, dtype=x.dtype)
+    if spec.kind == "conv":
+        mode, pm = L.GATHER_DIRECT, (L.PAD_REFLECT if spec.reflect else L.PAD_ZERO)
+    else:
+        mode, pm = L.GATHER_TRANSPOSED, L.PAD_ZERO
+    L.check(L.lib().uig_conv_gather(_p(x), _p(wp_fwd), _p(bias), _p(y), B, H, W, C, spec.cout, spec.k, spec.k,
+                                    spec.stride, spec.pad, pm, mode, Ho, Wo, spec.cout_store, spec.cout_store,
+                                    spec.act, spec.slope, _dt(x), _stream()), "uig_conv_gather(fwd)")
+    return y
+
+
+def _dy_padded(spec: ConvSpec, dy: torch.Tensor) -> torch.Tensor:
+    """dy as the backward kernels want it: (B,Ho,Wo,cout_p) contiguous (pads the 1-channel discriminator head)."""
+    if dy.shape[3] == spec.cout_p and dy.is_contiguous():
+        return dy
+    B, Ho, Wo, c = dy.shape
+    return to_nhwc(dy.permute(0, 3, 1, 2), dy.dtype, spec.cout_p)
+
+
+def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw) -> torch.Tensor:
+    """aten::convolution_backward, input gradient.  dy: (B,Ho,Wo,cout_p)."""
+    B, Ho, Wo, Cd = dy.shape
+    H, W = in_hw
+    lib, s = L.lib(), _stream()
+    if spec.kind == "convT":     # gradient of a transposed conv = strided direct conv of dy
+        dx = torch.empty((B, H, W, spec.cin_p), device=dy.device, dtype=dy.dtype)
+        L.check(lib.uig_conv_gather(_p(dy), _p(wp_dgrad), None, _p(dx), B, Ho, Wo, Cd, spec.cin, spec.k, spec.k, spec.stride,
+                                    spec.pad, L.PAD_ZERO, L.GATHER_DIRECT, H, W, spec.cin_p, spec.cin_p, L.ACT_NONE, 0.0,
+                                    _dt(dy), s), "uig_conv_gather(convT dgrad)")
+        return dx
+    if spec.reflect:             # gradient w.r.t. the reflection-padded input, then fold the border back
+        P = spec.pad
+        dxp = torch.empty((B, H + 2 * P, W + 2 * P, spec.cin_p), device=dy.device, dtype=dy.dtype)
+        L.check(lib.uig_conv_gather(_p(dy), _p(wp_dgrad), None, _p(dxp), B, Ho, Wo, Cd, spec.cin, spec.k, spec.k, spec.stride,
+                                    0, L.PAD_ZERO, L.GATHER_TRANSPOSED, H + 2 * P, W + 2 * P, spec.cin_p, spec.cin_p,
+                                    L.ACT_NONE, 0.0, _dt(dy), s), "uig_conv_gather(dgrad)")
+        dx = torch.empty((B, H, W, spec.cin_p), device=dy.device, dtype=dy.dtype)
+        L.check(lib.uig_reflect_fold(_p(dxp), _p(dx), B, H, W, spec.cin_p, P, _dt(dy), s), "uig_reflect_fold")
+        return dx
+    dx = torch.empty((B, H, W, spec.cin_p), device=dy.device, dtype=dy.dtype)
+    L.check(lib.uig_conv_gather(_p(dy), _p(wp_dgrad), None, _p(dx), B, Ho, Wo, Cd, spec.cin, spec.k, spec.k, spec.stride,
+                                spec.pad, L.PAD_ZERO, L.GATHER_TRANSPOSED, H, W, spec.cin_p, spec.cin_p, L.ACT_NONE, 0.0,
+                                _dt(dy), s), "uig_conv_gather(dgrad)")
+    return dx
+
+
+def _wgrad_splits(tiles: int, M: int) -> int:
+    return max(1, min(512 // max(tiles, 1), M // 128))
+
+
+def conv_wgrad(spec: ConvSpec, x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """aten::convolution_backward, weight gradient (fp32, torch layout)."""
+    lib, s = L.lib(), _stream()
+    B, H, W, _ = x.shape
+    _, Ho, Wo, _ = dy.shape
+    k = spec.k
+    if spec.kind == "conv":      # dense = dy, gathered = x;  dW (Cout, Cin, k, k)
+        Pt, Qt, Mh, Mw, Np, Hq, Wq, Cq = dy, x, Ho, Wo, spec.cout_p, H, W, spec.cin_p
+        pm = L.PAD_REFLECT if spec.reflect else L.PAD_ZERO
+        D0, D1 = spec.cout, spec.cin
+    else:                        # dense = x, gathered = dy;  dW (Cin, Cout, k, k)
+        Pt, Qt, Mh, Mw, Np, Hq, Wq, Cq = x, dy, H, W, spec.cin_p, Ho, Wo, spec.cout_p
+        pm = L.PAD_ZERO
+        D0, D1 = spec.cin, spec.cout
+    bn = 16 if Np <= 16 else 128
+    tiles = ((Np + bn - 1) // bn) * ((k * k * Cq + 127) // 128)
+    splits = _wgrad_splits(tiles, B * Mh * Mw)
+    ws = torch.empty((splits * Np * k * k * Cq,), device=x.device, dtype=torch.float32)
+    L.check(lib.uig_wgrad_partial(_p(Pt), _p(Qt), _p(ws), B, Mh, Mw, Np, Hq, Wq, Cq, k, k, spec.stride, spec.pad, pm,
+                                  splits, _dt(x), s), "uig_wgrad_partial")
+    dW = torch.empty(spec.weight_shape(), device=x.device, dtype=torch.float32)
+    L.check(lib.uig_wgrad_reduce(_p(ws), _p(dW), Np, Cq, k * k, splits, D0, D1, 0, s), "uig_wgrad_reduce")
+    return dW
+
+
+def bias_grad(dy: torch.Tensor, nreal: int) -> torch.Tensor:
+    B, Ho, Wo, C = dy.shape
+    ws = torch.empty((int(L.lib().uig_colsum_workspace_floats(C)),), device=dy.device, dtype=torch.float32)
+    db = torch.empty((nreal,), device=dy.device, dtype=torch.float32)
+    L.check(L.lib().uig_bias_grad(_p(dy), _p(db), _p(ws), B * Ho * Wo, C, nreal, 0, _dt(dy), _stream()), "uig_bias_grad")
+    return db
+
+
+class ConvFn(Function):
+    """y = act(conv(x, W) + b) on physical NHWC tensors; backward = dgrad / wgrad / bias-grad HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, layer):
+        spec = layer.spec
+        y = conv_forward(spec, x, layer.wp_fwd, bias)
+        ctx.layer, ctx.in_hw = layer, (x.shape[1], x.shape[2])
+        ctx.save_for_backward(x, y if spec.act != L.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        layer = ctx.layer
+        spec = layer.spec
+        x, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        if spec.act != L.ACT_NONE:      # epilogue activation backward on the saved output
+            g = torch.empty_like(dy)
+            L.check(L.lib().uig_act_bwd(_p(dy), _p(y), _p(g), dy.numel(), spec.act, spec.slope, _dt(dy), _stream()), "uig_act_bwd")
+            dy = g
+        dy = _dy_padded(spec, dy)
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv_dgrad(spec, dy, layer.wp_dgrad, ctx.in_hw)
+        if ctx.needs_input_grad[1]:
+            dW = conv_wgrad(spec, x, dy)
+        if ctx.needs_input_grad[2]:
+            db = bias_grad(dy, spec.cout)
+        return dx, dW, db, None
+
+
+# ----------------------------------------------------------------------------------------- instance norm (+act, +residual)
+class InstNormActFn(Function):
+    @staticmethod
+    def forward(ctx, x, residual, act, slope, eps):
+        _chk_phys(x, "instnorm")
+        B, H, W, C = x.shape
+        lib = L.lib()
+        ws = torch.empty((int(lib.uig_instnorm_workspace_floats(B, H * W, C)),), device=x.device, dtype=torch.float32)
+        stats = torch.empty((B, C, 2), device=x.device, dtype=torch.float32)
+        y = torch.empty_like(x)
+        L.check(lib.uig_instnorm_act_fwd(_p(x), _p(residual), _p(y), _p(stats), _p(ws), B, H * W, C, eps, act, slope,
+                                         _dt(x), _stream()), "uig_instnorm_act_fwd")
+        ctx.act, ctx.slope, ctx.has_res = act, slope, residual is not None
+        ctx.save_for_backward(x, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, H, W, C = x.shape
+        lib = L.lib()
+        ws = torch.empty((int(lib.uig_instnorm_workspace_floats(B, H * W, C)),), device=x.device, dtype=torch.float32)
+        dx = torch.empty_like(x)
+        L.check(lib.uig_instnorm_act_bwd(_p(dy), _p(x), _p(stats), _p(dx), _p(ws), B, H * W, C, ctx.act, ctx.slope,
+                                         _dt(x), _stream()), "uig_instnorm_act_bwd")
+        return dx, (dy if ctx.has_res else None), None, None, None
+
+
+# ----------------------------------------------------------------------------------------- fused losses
+def _loss_ws(dev):
+    return torch.empty((int(L.lib().uig_loss_workspace_floats()),), device=dev, dtype=torch.float32)
+
+
+class L1LossFn(Function):
+    """weight * mean|a - b| over the n_real unpadded elements; the gradient is produced in the same pass."""
+
+    @staticmethod
+    def forward(ctx, a, b, weight, n_real):
+        loss = torch.empty((1,), device=a.device, dtype=torch.float32)
+        need = ctx.needs_input_grad[0]
+        grad = torch.empty_like(a) if need else None
+        L.check(L.lib().uig_l1_loss_fwd_bwd(_p(a), _p(b), _p(loss), _p(grad), _p(_loss_ws(a.device)), a.numel(), n_real,
+                                            weight, _dt(a), _stream()), "uig_l1_loss_fwd_bwd")
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        out = torch.empty_like(grad)
+        L.check(L.lib().uig_scale_by_scalar(_p(grad), _p(g.contiguous().float()), _p(out), grad.numel(), _dt(grad), _stream()), "uig_scale_by_scalar")
+        return out, None, None, None
+
+
+class MSEConstFn(Function):
+    """weight * mean((a - target)^2)  (LSGAN adversarial loss against a constant label)."""
+
+    @staticmethod
+    def forward(ctx, a, target, weight):
+        loss = torch.empty((1,), device=a.device, dtype=torch.float32)
+        need = ctx.needs_input_grad[0]
+        grad = torch.empty_like(a) if need else None
+        L.check(L.lib().uig_mse_const_fwd_bwd(_p(a), target, _p(loss), _p(grad), _p(_loss_ws(a.device)), a.numel(), weight,
+                                              _dt(a), _stream()), "uig_mse_const_fwd_bwd")
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        out = torch.empty_like(grad)
+        L.check(L.lib().uig_scale_by_scalar(_p(grad), _p(g.contiguous().float()), _p(out), grad.numel(), _dt(grad), _stream()), "uig_scale_by_scalar")
+        return out, None, None
+
+
+def l1_loss(a, b, weight=1.0, n_real=None):
+    return L1LossFn.apply(a, b, float(weight), int(a.numel() if n_real is None else n_real))
+
+
+def mse_const(a, target, weight=1.0):
+    return MSEConstFn.apply(a, float(target), float(weight))
+
+
+def adam_flat(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    L.check(L.lib().uig_adam_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, _stream()), "uig_adam_flat")
+
+
+def adam_flat_graph(p, g, m, v, lr, beta1, beta2, eps, state16, grad_scale=1.0):
+    """Adam whose step counter lives on the device (state16: 4 x int32/float32), so a captured graph can replay it."""
+    L.check(L.lib().uig_adam_flat_graph(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, _p(state16), grad_scale, _stream()), "uig_adam_flat_graph")
