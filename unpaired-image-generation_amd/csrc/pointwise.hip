@@ -290,7 +290,7 @@ __global__ void from_nhwc_kernel(const TS* __restrict__ src, TD* __restrict__ ds
 }
 extern "C" int uig_to_nhwc(const void* src, int src_dtype, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
                            void* dst, int B, int C, int H, int W, int Cp, int dtype, void* stream) {
-    UIG_CHECK_ARG(src && dst && Cp >= C && Cp % 8 == 0, "uig_to_nhwc: bad args (C=%d Cp=%d)", C, Cp);
+    UIG_CHECK_ARG(src && dst && Cp >= C, "uig_to_nhwc: bad args (C=%d Cp=%d)", C, Cp);
     const long total = (long)B * H * W * Cp;
     hipStream_t s = (hipStream_t)stream; const int g = grid_for(total, 2);
     if (src_dtype == UIG_F32 && dtype == UIG_F32) hipLaunchKernelGGL((to_nhwc_kernel<float, float>), dim3(g), dim3(256), 0, s, (const float*)src, sb, sc, sh, sw, (float*)dst, B, C, H, W, Cp);
@@ -303,7 +303,7 @@ extern "C" int uig_to_nhwc(const void* src, int src_dtype, int64_t sb, int64_t s
 }
 extern "C" int uig_from_nhwc(const void* src, int B, int C, int H, int W, int Cp, int dtype,
                              void* dst, int dst_dtype, int64_t sb, int64_t sc, int64_t sh, int64_t sw, void* stream) {
-    UIG_CHECK_ARG(src && dst && Cp >= C && Cp % 8 == 0, "uig_from_nhwc: bad args (C=%d Cp=%d)", C, Cp);
+    UIG_CHECK_ARG(src && dst && Cp >= C, "uig_from_nhwc: bad args (C=%d Cp=%d)", C, Cp);
     const long total = (long)B * C * H * W;
     hipStream_t s = (hipStream_t)stream; const int g = grid_for(total, 2);
     if (dtype == UIG_F32 && dst_dtype == UIG_F32) hipLaunchKernelGGL((from_nhwc_kernel<float, float>), dim3(g), dim3(256), 0, s, (const float*)src, (float*)dst, sb, sc, sh, sw, B, C, H, W, Cp);
