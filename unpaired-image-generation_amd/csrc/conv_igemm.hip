@@ -24,6 +24,7 @@ struct GatherDesc {
     int Ho, Wo, ldc, Nstore;
     int act; float slope;
     int cin_shift;
+    unsigned x_bytes, w_bytes;   // buffer sizes for the hardware range check
     int nphase;
     int ph_tap0[5];
     signed char ph_oh[4], ph_ow[4];
@@ -102,35 +103,62 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const T* __restrict__ x, 
     const int nk = (ktot + BK - 1) / BK;
 
     u32x4_t ra[RA], rb[RB];
-    int tap_l = 0, c0 = 0;   // running (tap, channel) of the K-step being loaded (non-small mode)
+    // Buffer descriptors (wave-uniform: kernel arguments only). Out-of-range voffset (0xFFFFFFFF) makes the hardware
+    // return zeros: zero padding and ragged tiles cost one select per tap instead of a predicated load per K-step.
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, d.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wp), 0, d.w_bytes, 0x00020000);
+    int tap_l = 0, c0 = 0;        // running (tap, channel) of the K-step being loaded (non-small mode)
+    unsigned xvo[RA], wvo[RB];    // per-row byte offsets of the current tap; the channel offset rides in the SGPR soffset
+    int wso = 0;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) wvo[i] = ((nmask >> i) & 1u) ? (unsigned)((wrow[i] + ch * E) * (int)sizeof(T)) : 0xFFFFFFFFu;
 
     auto load_tile = [&](int ks) {
-        int tl, c;
         if constexpr (SMALL_CIN) {
             const int kf = ks * BK + ch * E;
-            tl = kf >> d.cin_shift; c = kf & (Cin - 1);
+            const int tl = kf >> d.cin_shift, c = kf & (Cin - 1);
+            const bool kok = tl < ntap;
+            const int tap = tap0 + (kok ? tl : 0);
+            const int ddh = d.dh[tap], ddw = d.dw[tap], wtap = d.wt[tap];
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                int hi = hb[i] + ddh, wi = wb[i] + ddw;
+                bool ok = kok && ((vmask >> i) & 1u);
+                if (d.pad_mode == UIG_PAD_REFLECT) { hi = reflect_idx(hi, d.H); wi = reflect_idx(wi, d.W); }
+                else ok = ok && ((unsigned)hi < (unsigned)d.H) && ((unsigned)wi < (unsigned)d.W);
+                const unsigned off = ok ? (unsigned)(((ib[i] + hi * d.W + wi) * Cin + c) * (int)sizeof(T)) : 0xFFFFFFFFu;
+                ra[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0));
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const bool ok = kok && ((nmask >> i) & 1u);
+                const unsigned off = ok ? (unsigned)((wrow[i] + wtap * Cin + c) * (int)sizeof(T)) : 0xFFFFFFFFu;
+                rb[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsw, off, 0, 0));
+            }
         } else {
-            tl = tap_l; c = c0 + ch * E;
+            if (c0 == 0) {       // new tap (block-uniform branch): recompute the gather offsets once per Cin/BK K-steps
+                // readfirstlane makes the uniformity provable: scalar kernarg loads, no waterfall loops around the buffer ops
+                const int tap = __builtin_amdgcn_readfirstlane(tap0 + tap_l);
+                const int ddh = d.dh[tap], ddw = d.dw[tap];
+                wso = __builtin_amdgcn_readfirstlane((int)d.wt[tap] * Cin * (int)sizeof(T));
+                const bool refl = d.pad_mode == UIG_PAD_REFLECT;
+#pragma unroll
+                for (int i = 0; i < RA; ++i) {
+                    const int hi = hb[i] + ddh, wi = wb[i] + ddw;
+                    const bool inb = ((unsigned)hi < (unsigned)d.H) & ((unsigned)wi < (unsigned)d.W);
+                    const bool ok = (((vmask >> i) & 1u) != 0) & (refl | inb);
+                    const int hr = refl ? reflect_idx(hi, d.H) : hi, wr = refl ? reflect_idx(wi, d.W) : wi;
+                    const unsigned off = (unsigned)(((ib[i] + hr * d.W + wr) * Cin + ch * E) * (int)sizeof(T));
+                    xvo[i] = ok ? off : 0xFFFFFFFFu;
+                }
+            }
+            const int so = __builtin_amdgcn_readfirstlane(c0 * (int)sizeof(T));
+            const int wso2 = __builtin_amdgcn_readfirstlane(wso + so);
+#pragma unroll
+            for (int i = 0; i < RA; ++i) ra[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsx, xvo[i], so, 0));
+#pragma unroll
+            for (int i = 0; i < RB; ++i) rb[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvo[i], wso2, 0));
             c0 += BK; if (c0 >= Cin) { c0 = 0; ++tap_l; }
-        }
-        const bool kok = tl < ntap;
-        const int tap = tap0 + (kok ? tl : 0);
-        const int ddh = d.dh[tap], ddw = d.dw[tap], wtap = d.wt[tap];
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            int hi = hb[i] + ddh, wi = wb[i] + ddw;
-            bool ok = kok && ((vmask >> i) & 1u);
-            if (d.pad_mode == UIG_PAD_REFLECT) { hi = reflect_idx(hi, d.H); wi = reflect_idx(wi, d.W); }
-            else ok = ok && ((unsigned)hi < (unsigned)d.H) && ((unsigned)wi < (unsigned)d.W);
-            const long off = ((long)(ib[i] + hi * d.W + wi)) * Cin + c;
-            u32x4_t z = {0u, 0u, 0u, 0u};
-            ra[i] = ok ? *reinterpret_cast<const u32x4_t*>(x + off) : z;
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const bool ok = kok && ((nmask >> i) & 1u);
-            u32x4_t z = {0u, 0u, 0u, 0u};
-            rb[i] = ok ? *reinterpret_cast<const u32x4_t*>(wp + (long)wrow[i] + wtap * Cin + c) : z;
         }
     };
     auto store_tile = [&](int stage) {
@@ -269,7 +297,9 @@ extern "C" int uig_conv_gather(const void* x, const void* wp, const float* bias,
     UIG_CHECK_ARG(stride == 1 || stride == 2, "uig_conv_gather: stride=%d unsupported", stride);
     UIG_CHECK_ARG(Nrows >= 1 && Nstore >= 1 && Nstore <= ldc, "uig_conv_gather: bad N (Nrows=%d Nstore=%d ldc=%d)", Nrows, Nstore, ldc);
     UIG_CHECK_ARG(dtype == UIG_F32 || dtype == UIG_BF16, "uig_conv_gather: bad dtype %d", dtype);
-    UIG_CHECK_ARG((long)B * H * W * Cin < (1L << 31) && (long)B * Ho * Wo * ldc < (1L << 31), "uig_conv_gather: tensor too large for 32-bit pixel indexing");
+    const long esz = dtype == UIG_BF16 ? 2 : 4;
+    UIG_CHECK_ARG((long)B * H * W * Cin * esz < (1L << 32) - 64 && (long)B * Ho * Wo * ldc < (1L << 31) && (long)Nrows * kH * kW * Cin * esz < (1L << 32) - 64,
+                  "uig_conv_gather: tensor too large for 32-bit byte offsets");
     if (pad_mode == UIG_PAD_REFLECT)
         UIG_CHECK_ARG(gather_mode == UIG_GATHER_DIRECT && pad < H && pad < W, "uig_conv_gather: reflect pad needs direct mode and pad < dim");
     const int BKe = (dtype == UIG_BF16) ? 64 : 32;
@@ -280,6 +310,7 @@ extern "C" int uig_conv_gather(const void* x, const void* wp, const float* bias,
     d.Nrows = Nrows; d.ldw = kH * kW * Cin; d.Ho = Ho; d.Wo = Wo; d.ldc = ldc; d.Nstore = Nstore;
     d.act = act; d.slope = slope;
     d.cin_shift = 0; while ((1 << d.cin_shift) < Cin) ++d.cin_shift;
+    d.x_bytes = (unsigned)((long)B * H * W * Cin * esz); d.w_bytes = (unsigned)((long)Nrows * kH * kW * Cin * esz);
     if (gather_mode == UIG_GATHER_DIRECT) {
         UIG_CHECK_ARG(Ho == (H + 2 * pad - kH) / stride + 1 && Wo == (W + 2 * pad - kW) / stride + 1,
                       "uig_conv_gather: direct output %dx%d does not match input %dx%d k=%dx%d s=%d p=%d", Ho, Wo, H, W, kH, kW, stride, pad);

@@ -60,16 +60,27 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ x, 
 }
 
 // fin MODE 0: stats = (mean, rstd)   MODE 1: out = (mean_g, mean_gxhat)   MODE 2: db[c] (+)= sum (B folded into slabs)
-__global__ void in_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, int BC, int C, int nslab,
-                                   double inv_n, float eps, int mode, int nreal, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= BC) return;
-    const int b = i / C, c = i % C;
+// 256 threads = 32 (b,c) items x 8 slab lanes: coalesced 256-byte partial reads, fp64 combine through LDS.
+__global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, int BC,
+                                                           int C, int nslab, double inv_n, float eps, int mode, int nreal,
+                                                           int accumulate) {
+    __shared__ double sa[8][32], sq[8][32];
+    const int ci = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + ci;
     double a = 0.0, q = 0.0;
-    for (int s = 0; s < nslab; ++s) {
-        const float* p = partial + (((long)b * nslab + s) * C + c) * 2;
-        a += (double)p[0]; q += (double)p[1];
+    int b = 0, c = 0;
+    if (i < BC) {
+        b = i / C; c = i % C;
+        for (int s = sl; s < nslab; s += 8) {
+            const float* p = partial + (((long)b * nslab + s) * C + c) * 2;
+            a += (double)p[0]; q += (double)p[1];
+        }
     }
+    sa[sl][ci] = a; sq[sl][ci] = q;
+    __syncthreads();
+    if (sl != 0 || i >= BC) return;
+#pragma unroll
+    for (int s = 1; s < 8; ++s) { a += sa[s][ci]; q += sq[s][ci]; }
     if (mode == 0) {
         const double mean = a * inv_n;
         double var = q * inv_n - mean * mean;
@@ -148,7 +159,7 @@ __global__ __launch_bounds__(256) void in_apply_bwd_kernel(const T* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-static int stats_slabs(long HW, int CC) { return (int)std::max<long>(1, std::min<long>(128, HW * CC / (256 * 8))); }
+static int stats_slabs(long HW, int CC) { return (int)std::max<long>(1, std::min<long>(128, HW * CC / (256 * 16))); }
 static int apply_slabs(long HW, int CC) { return (int)std::max<long>(1, std::min<long>(2048, HW * CC / (256 * 4))); }
 
 static int check_in_args(const char* fn, int B, long HW, int C, int dtype, int* CC) {
@@ -179,7 +190,7 @@ extern "C" int uig_instnorm_act_fwd(const void* x, const void* residual, void* y
     else
         hipLaunchKernelGGL((in_stats_kernel<float, 0>), dim3(ns, B), dim3(256), 0, s, (const float*)x, (const float*)nullptr, (const float*)nullptr, workspace, (long)HW, C, CC, ns, 0, 0.f);
     UIG_LAUNCH_CHECK("uig_instnorm_act_fwd(stats)");
-    hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, workspace, stats, B * C, C, ns, 1.0 / (double)HW, eps, 0, 0, 0);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 31) / 32), dim3(256), 0, s, workspace, stats, B * C, C, ns, 1.0 / (double)HW, eps, 0, 0, 0);
     UIG_LAUNCH_CHECK("uig_instnorm_act_fwd(finalize)");
     if (dtype == UIG_BF16)
         hipLaunchKernelGGL((in_apply_fwd_kernel<bf16_t>), dim3(na, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, stats, (long)HW, C, CC, na, act, slope);
@@ -202,7 +213,7 @@ extern "C" int uig_instnorm_act_bwd(const void* dy, const void* x, const float* 
     else
         hipLaunchKernelGGL((in_stats_kernel<float, 1>), dim3(ns, B), dim3(256), 0, s, (const float*)x, (const float*)dy, stats, workspace, (long)HW, C, CC, ns, act, slope);
     UIG_LAUNCH_CHECK("uig_instnorm_act_bwd(stats)");
-    hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, workspace, gm, B * C, C, ns, 1.0 / (double)HW, 0.f, 1, 0, 0);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 31) / 32), dim3(256), 0, s, workspace, gm, B * C, C, ns, 1.0 / (double)HW, 0.f, 1, 0, 0);
     UIG_LAUNCH_CHECK("uig_instnorm_act_bwd(finalize)");
     if (dtype == UIG_BF16)
         hipLaunchKernelGGL((in_apply_bwd_kernel<bf16_t>), dim3(na, B), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, stats, gm, (long)HW, C, CC, na, act, slope);
@@ -224,7 +235,7 @@ extern "C" int uig_bias_grad(const void* dy, float* db, float* workspace, int64_
     else
         hipLaunchKernelGGL((in_stats_kernel<float, 0>), dim3(ns, 1), dim3(256), 0, s, (const float*)dy, (const float*)nullptr, (const float*)nullptr, workspace, (long)pixels, C, CC, ns, 0, 0.f);
     UIG_LAUNCH_CHECK("uig_bias_grad(partial)");
-    hipLaunchKernelGGL(in_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, workspace, db, C, C, ns, 1.0, 0.f, 2, Nreal, accumulate);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, workspace, db, C, C, ns, 1.0, 0.f, 2, Nreal, accumulate);
     UIG_LAUNCH_CHECK("uig_bias_grad(finalize)");
     return 0;
 }
