@@ -6,13 +6,13 @@
 //   D[n][m] = sum_k  Wp[n][k] * X[pix(m, tap(k))][c(k)]        k = (tap, c),  c contiguous (NHWC)
 //
 // Layout in HBM: activations NHWC (channels padded to 8), packed weights [N][tap][C]: both operands are
-// K-contiguous, so every lane moves 16-byte chunks.  Per K-step the block stages a BM-pixel x 128-byte im2col tile
-// and a BN-channel x 128-byte weight tile through registers into XOR-swizzled LDS (double buffered, one barrier per
-// K-step), and each of the 4 waves runs MFMA 16x16 tiles over its WM x WN sub-tile:
+// K-contiguous, so every lane moves 16-byte chunks.  Per K-step the block streams a BM-pixel x 128-byte im2col tile
+// and a BN-channel x 128-byte weight tile straight into XOR-swizzled LDS (buffer_load ... lds, double buffered, one
+// barrier per K-step), and each of the 4 waves runs MFMA 16x16 tiles over its WM x WN sub-tile:
 //   bf16: v_mfma_f32_16x16x32_bf16 (BK = 64),   f32: v_mfma_f32_16x16x4_f32 (BK = 32, exact f32 fmaf chain).
 // The weight tile is the MFMA A operand and the pixel tile the B operand, so each lane ends up holding 4
 // consecutive output channels of one pixel (8/16-byte stores into NHWC).
-// Reflection padding is resolved in the gather address map; zero padding by predication.
+// Reflection padding is resolved in the gather address map; zero padding and ragged tiles by the buffer range check.
 #include "uig_common.h"
 
 struct GatherDesc {
@@ -102,38 +102,48 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const T* __restrict__ x, 
     const int ktot = ntap * Cin;
     const int nk = (ktot + BK - 1) / BK;
 
-    u32x4_t ra[RA], rb[RB];
     // Buffer descriptors (wave-uniform: kernel arguments only). Out-of-range voffset (0xFFFFFFFF) makes the hardware
     // return zeros: zero padding and ragged tiles cost one select per tap instead of a predicated load per K-step.
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, d.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wp), 0, d.w_bytes, 0x00020000);
+    // Tiles go HBM/L2 -> LDS directly (buffer_load ... lds, 16 B per lane, no VGPR staging, no ds_write).  An LDS-DMA
+    // wave-instruction writes 1 KiB linearly = 8 rows x 128 B, lane L -> row L/8, chunk slot L%8, which is exactly this
+    // thread mapping (wave w, slot i covers rows 8w+32i .. +7).  The XOR swizzle that keeps the ds_read_b128 fragment
+    // reads conflict-free is applied on the SOURCE side: slot s of row r holds global chunk s ^ ((r>>1)&7).
+    const int chs = ch ^ ((lr >> 1) & 7);
+    const int wave_row = __builtin_amdgcn_readfirstlane(wave * 8);
     int tap_l = 0, c0 = 0;        // running (tap, channel) of the K-step being loaded (non-small mode)
     unsigned xvo[RA], wvo[RB];    // per-row byte offsets of the current tap; the channel offset rides in the SGPR soffset
     int wso = 0;
 #pragma unroll
-    for (int i = 0; i < RB; ++i) wvo[i] = ((nmask >> i) & 1u) ? (unsigned)((wrow[i] + ch * E) * (int)sizeof(T)) : 0xFFFFFFFFu;
+    for (int i = 0; i < RB; ++i) wvo[i] = ((nmask >> i) & 1u) ? (unsigned)((wrow[i] + chs * E) * (int)sizeof(T)) : 0xFFFFFFFFu;
 
-    auto load_tile = [&](int ks) {
+    typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
+    auto issue_tile = [&](int ks, int stage) {
+        lds_ptr_t sx = (lds_ptr_t)smem + stage * STAGE + wave_row * 128;
+        lds_ptr_t sw = sx + BM * 128;
         if constexpr (SMALL_CIN) {
-            const int kf = ks * BK + ch * E;
+            const int kf = ks * BK + chs * E;
             const int tl = kf >> d.cin_shift, c = kf & (Cin - 1);
             const bool kok = tl < ntap;
             const int tap = tap0 + (kok ? tl : 0);
             const int ddh = d.dh[tap], ddw = d.dw[tap], wtap = d.wt[tap];
+            const bool refl = d.pad_mode == UIG_PAD_REFLECT;
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
-                int hi = hb[i] + ddh, wi = wb[i] + ddw;
-                bool ok = kok && ((vmask >> i) & 1u);
-                if (d.pad_mode == UIG_PAD_REFLECT) { hi = reflect_idx(hi, d.H); wi = reflect_idx(wi, d.W); }
-                else ok = ok && ((unsigned)hi < (unsigned)d.H) && ((unsigned)wi < (unsigned)d.W);
-                const unsigned off = ok ? (unsigned)(((ib[i] + hi * d.W + wi) * Cin + c) * (int)sizeof(T)) : 0xFFFFFFFFu;
-                ra[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0));
+                const int hi = hb[i] + ddh, wi = wb[i] + ddw;
+                const bool inb = ((unsigned)hi < (unsigned)d.H) & ((unsigned)wi < (unsigned)d.W);
+                const bool ok = kok & (((vmask >> i) & 1u) != 0) & (refl | inb);
+                const int hr = refl ? reflect_idx(hi, d.H) : hi, wr = refl ? reflect_idx(wi, d.W) : wi;
+                const unsigned off = ok ? (unsigned)(((ib[i] + hr * d.W + wr) * Cin + c) * (int)sizeof(T)) : 0xFFFFFFFFu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(sx + i * 32 * 128), 16, (int)off, 0, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
-                const bool ok = kok && ((nmask >> i) & 1u);
+                if (wave_row + 32 * i >= BN) continue;       // wave-uniform: rows past the weight tile
+                const bool ok = kok & (((nmask >> i) & 1u) != 0);
                 const unsigned off = ok ? (unsigned)((wrow[i] + wtap * Cin + c) * (int)sizeof(T)) : 0xFFFFFFFFu;
-                rb[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsw, off, 0, 0));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(sw + i * 32 * 128), 16, (int)off, 0, 0, 0);
             }
         } else {
             if (c0 == 0) {       // new tap (block-uniform branch): recompute the gather offsets once per Cin/BK K-steps
@@ -148,31 +158,21 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const T* __restrict__ x, 
                     const bool inb = ((unsigned)hi < (unsigned)d.H) & ((unsigned)wi < (unsigned)d.W);
                     const bool ok = (((vmask >> i) & 1u) != 0) & (refl | inb);
                     const int hr = refl ? reflect_idx(hi, d.H) : hi, wr = refl ? reflect_idx(wi, d.W) : wi;
-                    const unsigned off = (unsigned)(((ib[i] + hr * d.W + wr) * Cin + ch * E) * (int)sizeof(T));
+                    const unsigned off = (unsigned)(((ib[i] + hr * d.W + wr) * Cin + chs * E) * (int)sizeof(T));
                     xvo[i] = ok ? off : 0xFFFFFFFFu;
                 }
             }
             const int so = __builtin_amdgcn_readfirstlane(c0 * (int)sizeof(T));
             const int wso2 = __builtin_amdgcn_readfirstlane(wso + so);
 #pragma unroll
-            for (int i = 0; i < RA; ++i) ra[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsx, xvo[i], so, 0));
+            for (int i = 0; i < RA; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(sx + i * 32 * 128), 16, (int)xvo[i], so, 0, 0);
 #pragma unroll
-            for (int i = 0; i < RB; ++i) rb[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvo[i], wso2, 0));
+            for (int i = 0; i < RB; ++i) {
+                if (wave_row + 32 * i >= BN) continue;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(sw + i * 32 * 128), 16, (int)wvo[i], wso2, 0, 0);
+            }
             c0 += BK; if (c0 >= Cin) { c0 = 0; ++tap_l; }
-        }
-    };
-    auto store_tile = [&](int stage) {
-        unsigned char* sx = smem + stage * STAGE;
-        unsigned char* sw = sx + BM * 128;
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            const int r = lr + 32 * i;
-            *reinterpret_cast<u32x4_t*>(sx + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4)) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const int r = lr + 32 * i;
-            if (r < BN) *reinterpret_cast<u32x4_t*>(sw + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4)) = rb[i];
         }
     };
 
@@ -186,12 +186,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const T* __restrict__ x, 
     const int l16 = lane & 15, q = lane >> 4;
     const int swz = (l16 >> 1) & 7;
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+    issue_tile(0, 0);
+    __syncthreads();          // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
     for (int ks = 0; ks < nk; ++ks) {
         const int cur = ks & 1;
-        if (ks + 1 < nk) load_tile(ks + 1);
+        if (ks + 1 < nk) issue_tile(ks + 1, cur ^ 1);      // next tile streams into the other stage while this one is consumed
         const unsigned char* sx = smem + cur * STAGE + (wm * WM + l16) * 128;
         const unsigned char* sw = smem + cur * STAGE + BM * 128 + (wn * WN + l16) * 128;
 #pragma unroll
@@ -207,7 +206,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const T* __restrict__ x, 
 #pragma unroll
                 for (int b = 0; b < MT; ++b) Mma<T>::run(wf[a], xf[b], acc[a][b]);
         }
-        if (ks + 1 < nk) store_tile(cur ^ 1);
         __syncthreads();
     }
 
@@ -249,6 +247,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const T* __restrict__ x, 
         }
     }
 }
+
+// explicit instantiations (host stubs + device code for every tile configuration the dispatcher uses)
+#define UIG_INST(T, BM, BN, WMV) \
+    template __global__ void igemm_kernel<T, BM, BN, WMV, true>(const T*, const T*, const float*, T*, const GatherDesc); \
+    template __global__ void igemm_kernel<T, BM, BN, WMV, false>(const T*, const T*, const float*, T*, const GatherDesc);
+UIG_INST(bf16_t, 256, 16, 4) UIG_INST(bf16_t, 128, 64, 2) UIG_INST(bf16_t, 128, 128, 2)
+UIG_INST(float, 256, 16, 4) UIG_INST(float, 128, 64, 2) UIG_INST(float, 128, 128, 2)
+#undef UIG_INST
 
 // ------------------------------------------------------------------------------------------------ host side
 template <typename T, int BM, int BN, int WAVES_M, bool SMALL>
