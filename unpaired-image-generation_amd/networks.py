@@ -45,6 +45,7 @@ class ConvLayer(nn.Module):
         self.register_buffer("wp_fwd", torch.zeros(sf, device=device, dtype=dtype), persistent=False)
         self.register_buffer("wp_dgrad", torch.zeros(sd, device=device, dtype=dtype), persistent=False)
         self._packed_version = None
+        self.fuse_grad_accum = True    # backward adds dW/db into an existing .grad in place (see ops.ConvFn.backward)
 
     def repack(self):
         ops.pack_weights(self.spec, self.weight.data, self.compute_dtype, self.wp_fwd, self.wp_dgrad)

@@ -178,8 +178,9 @@ def _wgrad_splits(tiles: int, M: int) -> int:
     return max(1, min(512 // max(tiles, 1), M // 128))
 
 
-def conv_wgrad(spec: ConvSpec, x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
-    """aten::convolution_backward, weight gradient (fp32, torch layout)."""
+def conv_wgrad(spec: ConvSpec, x: torch.Tensor, dy: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = False) -> torch.Tensor:
+    """aten::convolution_backward, weight gradient (fp32, torch layout).  With `out` the split-K reduce writes (or, with
+    accumulate=True, adds) straight into that tensor, e.g. the layer's slice of the flat gradient buffer."""
     lib, s = L.lib(), _stream()
     B, H, W, _ = x.shape
     _, Ho, Wo, _ = dy.shape
@@ -198,17 +199,21 @@ def conv_wgrad(spec: ConvSpec, x: torch.Tensor, dy: torch.Tensor) -> torch.Tenso
     ws = torch.empty((splits * Np * k * k * Cq,), device=x.device, dtype=torch.float32)
     L.check(lib.uig_wgrad_partial(_p(Pt), _p(Qt), _p(ws), B, Mh, Mw, Np, Hq, Wq, Cq, k, k, spec.stride, spec.pad, pm,
                                   splits, _dt(x), s), "uig_wgrad_partial")
-    dW = torch.empty(spec.weight_shape(), device=x.device, dtype=torch.float32)
-    L.check(lib.uig_wgrad_reduce(_p(ws), _p(dW), Np, Cq, k * k, splits, D0, D1, 0, s), "uig_wgrad_reduce")
-    return dW
+    if out is None:
+        out, accumulate = torch.empty(spec.weight_shape(), device=x.device, dtype=torch.float32), False
+    elif not (out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == tuple(spec.weight_shape())):
+        raise ValueError("conv_wgrad: `out` must be a contiguous fp32 tensor of the weight's shape")
+    L.check(lib.uig_wgrad_reduce(_p(ws), _p(out), Np, Cq, k * k, splits, D0, D1, 1 if accumulate else 0, s), "uig_wgrad_reduce")
+    return out
 
 
-def bias_grad(dy: torch.Tensor, nreal: int) -> torch.Tensor:
+def bias_grad(dy: torch.Tensor, nreal: int, out: torch.Tensor | None = None, accumulate: bool = False) -> torch.Tensor:
     B, Ho, Wo, C = dy.shape
     ws = torch.empty((int(L.lib().uig_colsum_workspace_floats(C)),), device=dy.device, dtype=torch.float32)
-    db = torch.empty((nreal,), device=dy.device, dtype=torch.float32)
-    L.check(L.lib().uig_bias_grad(_p(dy), _p(db), _p(ws), B * Ho * Wo, C, nreal, 0, _dt(dy), _stream()), "uig_bias_grad")
-    return db
+    if out is None:
+        out, accumulate = torch.empty((nreal,), device=dy.device, dtype=torch.float32), False
+    L.check(L.lib().uig_bias_grad(_p(dy), _p(out), _p(ws), B * Ho * Wo, C, nreal, 1 if accumulate else 0, _dt(dy), _stream()), "uig_bias_grad")
+    return out
 
 
 class ConvFn(Function):
@@ -236,10 +241,21 @@ class ConvFn(Function):
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad(spec, dy, layer.wp_dgrad, ctx.in_hw)
+        # Parameter gradients: when the parameter already owns a .grad buffer (the trainer's flat gradient buffer, or any
+        # earlier backward) the reduce kernels ADD into it in place and autograd gets None (= nothing more to accumulate):
+        # gradient-accumulation fusion, no temporary dW and no extra add kernel.  Otherwise return them the usual way.
         if ctx.needs_input_grad[1]:
-            dW = conv_wgrad(spec, x, dy)
+            w = layer.weight
+            if layer.fuse_grad_accum and w.grad is not None and w.grad.is_contiguous():
+                conv_wgrad(spec, x, dy, out=w.grad, accumulate=True)
+            else:
+                dW = conv_wgrad(spec, x, dy)
         if ctx.needs_input_grad[2]:
-            db = bias_grad(dy, spec.cout)
+            b = layer.bias
+            if layer.fuse_grad_accum and b.grad is not None and b.grad.is_contiguous():
+                bias_grad(dy, spec.cout, out=b.grad, accumulate=True)
+            else:
+                db = bias_grad(dy, spec.cout)
         return dx, dW, db, None
 
 
