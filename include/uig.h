@@ -36,6 +36,8 @@ enum { UIG_PACK_ROW_DIM0 = 0, UIG_PACK_ROW_DIM1 = 1 };
 const char* uig_version(void);
 const char* uig_last_error(void);
 int uig_device_ok(void); /* 1 if a gfx950 device is visible to the HIP runtime */
+/* tuning / test hook: force the conv tile width for layers with >64 output channels (0 = auto, 128, 256) */
+void uig_debug_set_tile(int bn);
 
 /* aten::convolution / aten::convolution_backward(input grad) — implicit GEMM, LDS-staged im2col tiles -> MFMA.
  *   y[b, oh, ow, n] = act( bias[n] + sum_{tap,c} x[b, ih(tap), iw(tap), c] * wp[n][tap][c] )

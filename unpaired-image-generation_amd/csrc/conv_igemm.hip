@@ -28,8 +28,7 @@ struct GatherDesc {
     int nphase;
     int ph_tap0[5];
     signed char ph_oh[4], ph_ow[4];
-    signed char dh[64], dw[64];
-    unsigned char wt[64];
+    int tap[64];           // per tap: (dh + 128) | (dw + 128) << 8 | weight-tap-index << 16  (one scalar dword load)
 };
 
 template <typename T> struct Mma;
@@ -46,18 +45,24 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T, int BM, int BN, int WAVES_M, bool SMALL_CIN>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const T* __restrict__ x, const T* __restrict__ wp,
-                                                        const float* __restrict__ bias, T* __restrict__ y,
-                                                        const GatherDesc d) {
+// Tile configuration: BM pixels x BN channels per block, WAVES_M x WAVES_N waves (64 threads each), NSTAGE LDS stages.
+// NSTAGE == 2: one tile in flight behind the one being consumed (drained with vmcnt(0) each K-step).
+// NSTAGE >= 3: NSTAGE-1 tiles in flight; a COUNTED s_waitcnt vmcnt(N) retires only the oldest tile and a raw s_barrier
+//              (no implicit drain) orders it for the other waves' ds_reads: the LDS-DMA stream never stops.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, bool SMALL_CIN>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2)
+void igemm_kernel(const T* __restrict__ x, const T* __restrict__ wp, const float* __restrict__ bias, T* __restrict__ y,
+                  const GatherDesc d) {
     constexpr int E = ElemTraits<T>::E;
     constexpr int BK = 8 * E;                 // 128 bytes of K per row per step
-    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int NWAVES = WAVES_M * WAVES_N, RPP = NWAVES * 8;     // rows staged per pass of the whole block
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MT = WM / 16, NT = WN / 16;
-    constexpr int RA = BM / 32, RB = (BN + 31) / 32;
+    constexpr int RA = BM / RPP, RB = (BN + RPP - 1) / RPP;
     constexpr int STAGE = (BM + BN) * 128;
     static_assert(WM % 16 == 0 && WN % 16 == 0, "wave tile must be a multiple of the 16x16 MFMA tile");
+    static_assert(BM % RPP == 0, "BM must be a multiple of the rows staged per pass");
+    static_assert(NSTAGE == 2 || BN % RPP == 0, "counted vmcnt needs every wave to issue the same number of DMAs");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const T* __restrict__ x, 
     unsigned vmask = 0;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int m = m_base + lr + 32 * i;
+        const int m = m_base + lr + RPP * i;
         const bool v = m < M;
         const int mm = v ? m : 0;
         const int jj = mm % d.Mw, t = mm / d.Mw, ii = t % d.Mh, b = t / d.Mh;
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const T* __restrict__ x, 
     unsigned nmask = 0;
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-        const int r = lr + 32 * i, n = n_base + r;
+        const int r = lr + RPP * i, n = n_base + r;
         const bool v = (r < BN) && (n < d.Nrows);
         wrow[i] = (v ? n : 0) * d.ldw;
         nmask |= (v ? 1u : 0u) << i;
@@ -127,7 +132,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const T* __restrict__ x, 
             const int tl = kf >> d.cin_shift, c = kf & (Cin - 1);
             const bool kok = tl < ntap;
             const int tap = tap0 + (kok ? tl : 0);
-            const int ddh = d.dh[tap], ddw = d.dw[tap], wtap = d.wt[tap];
+            const int te = d.tap[tap];
+            const int ddh = (te & 255) - 128, ddw = ((te >> 8) & 255) - 128, wtap = te >> 16;
             const bool refl = d.pad_mode == UIG_PAD_REFLECT;
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
@@ -136,21 +142,22 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const T* __restrict__ x, 
                 const bool ok = kok & (((vmask >> i) & 1u) != 0) & (refl | inb);
                 const int hr = refl ? reflect_idx(hi, d.H) : hi, wr = refl ? reflect_idx(wi, d.W) : wi;
                 const unsigned off = ok ? (unsigned)(((ib[i] + hr * d.W + wr) * Cin + c) * (int)sizeof(T)) : 0xFFFFFFFFu;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(sx + i * 32 * 128), 16, (int)off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(sx + i * RPP * 128), 16, (int)off, 0, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
-                if (wave_row + 32 * i >= BN) continue;       // wave-uniform: rows past the weight tile
+                if constexpr (BN % RPP != 0) { if (wave_row + RPP * i >= BN) continue; }       // wave-uniform: rows past the weight tile
                 const bool ok = kok & (((nmask >> i) & 1u) != 0);
                 const unsigned off = ok ? (unsigned)((wrow[i] + wtap * Cin + c) * (int)sizeof(T)) : 0xFFFFFFFFu;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(sw + i * 32 * 128), 16, (int)off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(sw + i * RPP * 128), 16, (int)off, 0, 0, 0);
             }
         } else {
             if (c0 == 0) {       // new tap (block-uniform branch): recompute the gather offsets once per Cin/BK K-steps
                 // readfirstlane makes the uniformity provable: scalar kernarg loads, no waterfall loops around the buffer ops
                 const int tap = __builtin_amdgcn_readfirstlane(tap0 + tap_l);
-                const int ddh = d.dh[tap], ddw = d.dw[tap];
-                wso = __builtin_amdgcn_readfirstlane((int)d.wt[tap] * Cin * (int)sizeof(T));
+                const int te = __builtin_amdgcn_readfirstlane(d.tap[tap]);
+                const int ddh = (te & 255) - 128, ddw = ((te >> 8) & 255) - 128;
+                wso = __builtin_amdgcn_readfirstlane((te >> 16) * Cin * (int)sizeof(T));
                 const bool refl = d.pad_mode == UIG_PAD_REFLECT;
 #pragma unroll
                 for (int i = 0; i < RA; ++i) {
@@ -166,11 +173,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const T* __restrict__ x, 
             const int wso2 = __builtin_amdgcn_readfirstlane(wso + so);
 #pragma unroll
             for (int i = 0; i < RA; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(sx + i * 32 * 128), 16, (int)xvo[i], so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(sx + i * RPP * 128), 16, (int)xvo[i], so, 0, 0);
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
-                if (wave_row + 32 * i >= BN) continue;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(sw + i * 32 * 128), 16, (int)wvo[i], wso2, 0, 0);
+                if constexpr (BN % RPP != 0) { if (wave_row + RPP * i >= BN) continue; }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(sw + i * RPP * 128), 16, (int)wvo[i], wso2, 0, 0);
             }
             c0 += BK; if (c0 >= Cin) { c0 = 0; ++tap_l; }
         }
@@ -186,11 +193,23 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const T* __restrict__ x, 
     const int l16 = lane & 15, q = lane >> 4;
     const int swz = (l16 >> 1) & 7;
 
-    issue_tile(0, 0);
-    __syncthreads();          // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
+    // ---- main loop: NSTAGE-deep ring of LDS stages filled by LDS-DMA, one barrier per K-step
+    constexpr int PER_TILE = RA + RB;                       // DMA instructions per wave per tile
+#pragma unroll
+    for (int st = 0; st < NSTAGE - 1; ++st)
+        if (st < nk) issue_tile(st, st);
     for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1;
-        if (ks + 1 < nk) issue_tile(ks + 1, cur ^ 1);      // next tile streams into the other stage while this one is consumed
+        // retire tile ks: this wave's own DMAs by vmcnt, the other waves' by the barrier behind it
+        if constexpr (NSTAGE == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (ks + NSTAGE - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 2) * PER_TILE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        // every wave is past its reads of stage (ks-1) % NSTAGE: refill it with tile ks + NSTAGE - 1
+        if (ks + NSTAGE - 1 < nk) issue_tile(ks + NSTAGE - 1, (ks + NSTAGE - 1) % NSTAGE);
+        const int cur = ks % NSTAGE;
         const unsigned char* sx = smem + cur * STAGE + (wm * WM + l16) * 128;
         const unsigned char* sw = smem + cur * STAGE + BM * 128 + (wn * WN + l16) * 128;
 #pragma unroll
@@ -206,7 +225,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const T* __restrict__ x, 
 #pragma unroll
                 for (int b = 0; b < MT; ++b) Mma<T>::run(wf[a], xf[b], acc[a][b]);
         }
-        __syncthreads();
     }
 
     // ---- epilogue: lane holds channels n..n+3 (rows 4q+reg of the 16x16 tile) of pixel column l16
@@ -249,45 +267,54 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const T* __restrict__ x, 
 }
 
 // explicit instantiations (host stubs + device code for every tile configuration the dispatcher uses)
-#define UIG_INST(T, BM, BN, WMV) \
-    template __global__ void igemm_kernel<T, BM, BN, WMV, true>(const T*, const T*, const float*, T*, const GatherDesc); \
-    template __global__ void igemm_kernel<T, BM, BN, WMV, false>(const T*, const T*, const float*, T*, const GatherDesc);
-UIG_INST(bf16_t, 256, 16, 4) UIG_INST(bf16_t, 128, 64, 2) UIG_INST(bf16_t, 128, 128, 2)
-UIG_INST(float, 256, 16, 4) UIG_INST(float, 128, 64, 2) UIG_INST(float, 128, 128, 2)
+#define UIG_INST(T, BM, BN, WMV, WNV, NS) \
+    template __global__ void igemm_kernel<T, BM, BN, WMV, WNV, NS, true>(const T*, const T*, const float*, T*, const GatherDesc); \
+    template __global__ void igemm_kernel<T, BM, BN, WMV, WNV, NS, false>(const T*, const T*, const float*, T*, const GatherDesc);
+UIG_INST(bf16_t, 256, 16, 4, 1, 2) UIG_INST(bf16_t, 128, 64, 2, 2, 2) UIG_INST(bf16_t, 128, 128, 2, 2, 2) UIG_INST(bf16_t, 128, 256, 2, 4, 3)
+UIG_INST(float, 256, 16, 4, 1, 2) UIG_INST(float, 128, 64, 2, 2, 2) UIG_INST(float, 128, 128, 2, 2, 2) UIG_INST(float, 128, 256, 2, 4, 3)
 #undef UIG_INST
 
 // ------------------------------------------------------------------------------------------------ host side
-template <typename T, int BM, int BN, int WAVES_M, bool SMALL>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, bool SMALL>
 static int launch_igemm(const void* x, const void* wp, const float* bias, void* y, const GatherDesc& d, hipStream_t s) {
     const int M = d.B * d.Mh * d.Mw;
     const int mt = (M + BM - 1) / BM, nt = (d.Nrows + BN - 1) / BN;
-    const size_t smem = 2 * (size_t)(BM + BN) * 128;
-    auto kern = igemm_kernel<T, BM, BN, WAVES_M, SMALL>;
+    const size_t smem = NSTAGE * (size_t)(BM + BN) * 128;
+    auto kern = igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, NSTAGE, SMALL>;
     static bool attr_done = false;   // benign race: idempotent
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return uig_set_error((int)e, "igemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(mt * nt, d.nphase), dim3(256), smem, s,
+    hipLaunchKernelGGL(kern, dim3(mt * nt, d.nphase), dim3(64 * WAVES_M * WAVES_N), smem, s,
                        (const T*)x, (const T*)wp, bias, (T*)y, d);
     UIG_LAUNCH_CHECK("uig_conv_gather");
     return 0;
 }
+
+static int g_force_tile = 0;   // testing / tuning hook: 0 = auto, 128 / 256 = force that BN for wide layers
+extern "C" void uig_debug_set_tile(int bn) { g_force_tile = bn; }
 
 template <typename T>
 static int dispatch_igemm(const void* x, const void* wp, const float* bias, void* y, const GatherDesc& d, hipStream_t s) {
     constexpr int BK = 8 * ElemTraits<T>::E;
     const bool small = d.Cin < BK || (d.Cin % BK) != 0;
     if (d.Nrows <= 16) {
-        return small ? launch_igemm<T, 256, 16, 4, true>(x, wp, bias, y, d, s)
-                     : launch_igemm<T, 256, 16, 4, false>(x, wp, bias, y, d, s);
+        return small ? launch_igemm<T, 256, 16, 4, 1, 2, true>(x, wp, bias, y, d, s)
+                     : launch_igemm<T, 256, 16, 4, 1, 2, false>(x, wp, bias, y, d, s);
     } else if (d.Nrows <= 64) {
-        return small ? launch_igemm<T, 128, 64, 2, true>(x, wp, bias, y, d, s)
-                     : launch_igemm<T, 128, 64, 2, false>(x, wp, bias, y, d, s);
+        return small ? launch_igemm<T, 128, 64, 2, 2, 2, true>(x, wp, bias, y, d, s)
+                     : launch_igemm<T, 128, 64, 2, 2, 2, false>(x, wp, bias, y, d, s);
     }
-    return small ? launch_igemm<T, 128, 128, 2, true>(x, wp, bias, y, d, s)
-                 : launch_igemm<T, 128, 128, 2, false>(x, wp, bias, y, d, s);
+    // Measured on MI355X (ResBlock conv, batch 8): 128x128 / 4 waves / 2 blocks per CU = 701 TF, 128x256 / 8 waves / 3-stage
+    // ring = 683 TF (both limited by the per-CU L2->LDS path), so the narrow tile stays the default.
+    const bool wide = g_force_tile == 256;
+    if (wide)      // full-width tile: the im2col tile is staged once per pixel tile, 8 waves, 3-stage DMA ring
+        return small ? launch_igemm<T, 128, 256, 2, 4, 3, true>(x, wp, bias, y, d, s)
+                     : launch_igemm<T, 128, 256, 2, 4, 3, false>(x, wp, bias, y, d, s);
+    return small ? launch_igemm<T, 128, 128, 2, 2, 2, true>(x, wp, bias, y, d, s)
+                 : launch_igemm<T, 128, 128, 2, 2, 2, false>(x, wp, bias, y, d, s);
 }
 
 static int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
@@ -325,7 +352,7 @@ extern "C" int uig_conv_gather(const void* x, const void* wp, const float* bias,
         for (int kh = 0; kh < kH; ++kh)
             for (int kw = 0; kw < kW; ++kw) {
                 const int t = kh * kW + kw;
-                d.dh[t] = (signed char)(kh - pad); d.dw[t] = (signed char)(kw - pad); d.wt[t] = (unsigned char)t;
+                d.tap[t] = ((kh - pad) + 128) | (((kw - pad) + 128) << 8) | (t << 16);
             }
     } else {
         UIG_CHECK_ARG(gather_mode == UIG_GATHER_TRANSPOSED, "uig_conv_gather: bad gather_mode %d", gather_mode);
@@ -342,9 +369,7 @@ extern "C" int uig_conv_gather(const void* x, const void* wp, const float* bias,
                     if (((a + pad - kh) % stride + stride) % stride) continue;
                     for (int kw = 0; kw < kW; ++kw) {
                         if (((b + pad - kw) % stride + stride) % stride) continue;
-                        d.dh[nt] = (signed char)floordiv(a + pad - kh, stride);
-                        d.dw[nt] = (signed char)floordiv(b + pad - kw, stride);
-                        d.wt[nt] = (unsigned char)(kh * kW + kw);
+                        d.tap[nt] = (floordiv(a + pad - kh, stride) + 128) | ((floordiv(b + pad - kw, stride) + 128) << 8) | ((kh * kW + kw) << 16);
                         ++nt;
                     }
                 }
