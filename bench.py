@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=50)
+    ap.add_argument("--force-comm", action="store_true", help="run the RCCL exchange even at world size 1 (plumbing test)")
     args = ap.parse_args()
 
     import torch
@@ -47,9 +48,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or args.force_comm:
         assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
@@ -59,7 +62,7 @@ def main():
     assert u.lib.lib().uig_device_ok() == 1, "bench.py needs an MI355X (gfx950)"
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(0)                                   # identical replicas on every rank
-    model = u.CycleGAN(n_blocks=9, dtype=dtype, device=dev, use_graph=not args.no_graph)
+    model = u.CycleGAN(n_blocks=9, dtype=dtype, device=dev, use_graph=not args.no_graph, force_exchange=args.force_comm)
     model.broadcast_params(0)
     torch.manual_seed(1000 + rank)                         # different data shard per rank
     B, S = args.batch, args.size
@@ -106,7 +109,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch, S)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

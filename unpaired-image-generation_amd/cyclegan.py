@@ -17,56 +17,27 @@ MI355X-first choices (all result-preserving because InstanceNorm statistics are 
 from __future__ import annotations
 
 import torch
-import torch.distributed as dist
 
 from . import ops
+from .dp import FlatGroup, GradExchange
 from .networks import Discriminator, Generator
 
 LOSS_NAMES = ("idt_A", "idt_B", "G_A", "G_B", "cyc_A", "cyc_B", "D_A", "D_B")
 
 
-class FlatGroup:
-    """All parameters of an optimiser group as views into one flat fp32 buffer (+ flat grad / Adam m, v)."""
-
-    def __init__(self, nets, device):
-        self.params = [p for n in nets for p in n.parameters()]
-        sizes = [(p.numel() + 3) // 4 * 4 for p in self.params]        # keep every view 16-byte aligned
-        total = sum(sizes)
-        self.flat = torch.zeros(total, device=device, dtype=torch.float32)
-        self.grad = torch.zeros(total, device=device, dtype=torch.float32)
-        self.m = torch.zeros(total, device=device, dtype=torch.float32)
-        self.v = torch.zeros(total, device=device, dtype=torch.float32)
-        off = 0
-        for p, sz in zip(self.params, sizes):
-            n = p.numel()
-            self.flat[off:off + n].copy_(p.data.reshape(-1))
-            p.data = self.flat[off:off + n].view(p.shape)
-            p.grad = self.grad[off:off + n].view(p.shape)
-            off += sz
-        self.step = 0
-
-    def zero_grad(self):
-        self.grad.zero_()
-
-    def set_requires_grad(self, flag: bool):
-        for p in self.params:
-            p.requires_grad_(flag)
-
-
 class CycleGAN:
     def __init__(self, n_blocks=9, dtype=torch.bfloat16, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-8,
-                 lambda_cyc=10.0, lambda_idt=0.5, device="cuda", process_group=None, use_graph=False, batch_fused=True):
+                 lambda_cyc=10.0, lambda_idt=0.5, device="cuda", process_group=None, use_graph=False, batch_fused=True, force_exchange=False):
         self.device, self.dtype = torch.device(device), dtype
         kw = dict(dtype=dtype, device=device)
         self.G_A, self.G_B = Generator(n_blocks=n_blocks, **kw), Generator(n_blocks=n_blocks, **kw)
         self.D_A, self.D_B = Discriminator(**kw), Discriminator(**kw)
         self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
         self.lam, self.lam_idt = lambda_cyc, lambda_idt
-        self.pg = process_group
-        self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
+        self.xchg = GradExchange(process_group, force=force_exchange)
+        self.world = self.xchg.world
         self.use_graph, self.batch_fused = use_graph, batch_fused
         self._graphs = None
-        self._comm_stream = None
         self._finalize_params()
 
     # ------------------------------------------------------------------ parameters
@@ -94,9 +65,9 @@ class CycleGAN:
             n.repack()
 
     def broadcast_params(self, src=0):
+        self.xchg.broadcast(self.grp_G.flat, src)
+        self.xchg.broadcast(self.grp_D.flat, src)
         if self.world > 1:
-            dist.broadcast(self.grp_G.flat, src, group=self.pg)
-            dist.broadcast(self.grp_D.flat, src, group=self.pg)
             self.repack()
 
     # ------------------------------------------------------------------ step pieces (all async, static shapes)
@@ -145,32 +116,16 @@ class CycleGAN:
         grp.step += 1
         ops.adam_flat(grp.flat, grp.grad, grp.m, grp.v, self.lr, self.b1, self.b2, self.eps, grp.step, 1.0 / self.world)
 
-    def _allreduce(self, grp):
-        """sum-all-reduce of one flat gradient buffer on the communication stream (RCCL over xGMI)."""
-        if self.world <= 1:
-            return None
-        if self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream(device=self.device)
-        cur = torch.cuda.current_stream()
-        self._comm_stream.wait_stream(cur)
-        with torch.cuda.stream(self._comm_stream):
-            dist.all_reduce(grp.grad, op=dist.ReduceOp.SUM, group=self.pg)
-        ev = torch.cuda.Event()
-        ev.record(self._comm_stream)
-        return ev
-
     # ------------------------------------------------------------------ the step
     def _step_eager(self, xa, xb):
         self.repack()
         fake_B, fake_A, lg = self._g_phase(xa, xb)
-        ev_g = self._allreduce(self.grp_G)               # overlaps the whole discriminator phase
+        h_g = self.xchg.start(self.grp_G.grad)           # overlaps the whole discriminator phase
         ld = self._d_phase(xa, xb, fake_B, fake_A)
-        if ev_g is not None:
-            torch.cuda.current_stream().wait_event(ev_g)
-        ev_d = self._allreduce(self.grp_D)               # overlaps the generator Adam
+        self.xchg.wait(h_g, self.device)
+        h_d = self.xchg.start(self.grp_D.grad)           # overlaps the generator Adam
         self._adam(self.grp_G)
-        if ev_d is not None:
-            torch.cuda.current_stream().wait_event(ev_d)
+        self.xchg.wait(h_d, self.device)
         self._adam(self.grp_D)
         l_D_A = ld[0][0] + ld[0][1]
         l_D_B = ld[1][0] + ld[1][1]
@@ -190,8 +145,4 @@ class CycleGAN:
         self.last_losses = losses
         if not sync:
             return losses
-        if self.world > 1:
-            losses = losses.clone()
-            dist.all_reduce(losses, op=dist.ReduceOp.SUM, group=self.pg)
-            losses /= self.world
-        return dict(zip(LOSS_NAMES, losses.tolist()))
+        return dict(zip(LOSS_NAMES, self.xchg.mean_scalars(losses).tolist()))

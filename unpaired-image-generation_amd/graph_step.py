@@ -63,16 +63,13 @@ def graph_train_step(model, real_A, real_B):
         st = model._graphs = _capture(model, real_A, real_B)
     st.real_A.copy_(real_A, non_blocking=True)
     st.real_B.copy_(real_B, non_blocking=True)
-    cur = torch.cuda.current_stream()
     st.g1.replay()
-    ev_g = model._allreduce(model.grp_G)          # overlaps the discriminator graph
+    h_g = model.xchg.start(model.grp_G.grad)      # overlaps the discriminator graph
     st.g2.replay()
-    if ev_g is not None:
-        cur.wait_event(ev_g)
-    ev_d = model._allreduce(model.grp_D)          # overlaps the generator Adam
+    model.xchg.wait(h_g, model.device)
+    h_d = model.xchg.start(model.grp_D.grad)      # overlaps the generator Adam
     st.g3.replay()
-    if ev_d is not None:
-        cur.wait_event(ev_d)
+    model.xchg.wait(h_d, model.device)
     st.g4.replay()
     model.grp_G.step += 1
     model.grp_D.step += 1
