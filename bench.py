@@ -133,9 +133,18 @@ def dominant_kernel_roofline(u, torch, dev, dtype, nimg, hw, iters):
     flops = 2.0 * nimg * hw * hw * 256 * 2304
     peak = PEAK_BF16 if dtype == torch.bfloat16 else PEAK_F32
     ach = flops / (us * 1e-6)
+    # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs,
+    # gfx950 FETCH_SIZE x2 correction: scripts/prof_dominant.sh + scripts/pmc_summary.py); null when the shape differs.
+    traffic = None
+    try:
+        pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_dominant_pmc.json"))
+        if pmc and dtype == torch.bfloat16 and nimg == 8 and hw == 64:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", pmc[-1]))).get("hbm_bytes_per_launch")
+    except OSError:
+        pass
     return {"kernel": "igemm_kernel<bf16,128,128> conv3x3 256->256 reflect (ResBlock fwd)" if dtype == torch.bfloat16 else "igemm_kernel<f32,128,128>",
             "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
-            "frac": round(ach / peak, 4), "traffic": None, "avg_us": round(us, 2),
+            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes/launch (algorithmic 34.7e6)", "avg_us": round(us, 2),
             "gemm": f"M={nimg * hw * hw} N=256 K=2304", "flops_per_launch": flops}
 
 

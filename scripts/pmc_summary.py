@@ -1,0 +1,30 @@
+"""Summarise the rocprofv3 passes of scripts/prof_dominant.sh into profiles/<tag>_dominant_pmc.json.
+HBM traffic per launch follows MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE come from SEPARATE --pmc passes, are in
+KiB, and on gfx950 FETCH_SIZE counts 128-B read requests as 64 B for wide coalesced streams -> doubled; WRITE_SIZE is exact."""
+import csv, glob, json, sys, collections
+src, out = sys.argv[1], sys.argv[2]
+res = {"kernel": None, "launches": 0}
+for name in ("fetch", "write", "sq"):
+    f = glob.glob(f"{src}/{name}/*/*_counter_collection.csv")
+    if not f:
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        if "igemm_kernel" in r["Kernel_Name"]:
+            res["kernel"] = r["Kernel_Name"].split("(")[0]
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        res[k] = sum(v) / len(v); res["launches"] = len(v)
+st = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")
+if st:
+    for r in csv.DictReader(open(st[0])):
+        if "igemm_kernel" in r["Name"]:
+            res["avg_duration_us"] = float(r["AverageNs"]) / 1e3; res["calls"] = int(r["Calls"])
+if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
+    res["hbm_read_bytes_corrected"] = res["FETCH_SIZE"] * 1024 * 2
+    res["hbm_write_bytes"] = res["WRITE_SIZE"] * 1024
+    res["hbm_bytes_per_launch"] = res["hbm_read_bytes_corrected"] + res["hbm_write_bytes"]
+    res["algorithmic_bytes_per_launch"] = (8 * 64 * 64 * 256 * 2) * 2 + 256 * 2304 * 2
+res["workload"] = "ResBlock conv3x3 reflect 256->256 on 64x64, batch 8, bf16 (M=32768 N=256 K=2304)"
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))
