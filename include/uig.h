@@ -38,6 +38,10 @@ const char* uig_last_error(void);
 int uig_device_ok(void); /* 1 if a gfx950 device is visible to the HIP runtime */
 /* tuning / test hook: force the conv tile width for layers with >64 output channels (0 = auto, 128, 256) */
 void uig_debug_set_tile(int bn);
+/* tuning / test hook: 1 (default) = stride-1 3x3 convs use the LDS-resident-strip kernel, 0 = always the generic gather */
+void uig_debug_set_strip(int on);
+/* diagnostic build hook: device buffer (u64[blocks*8*4]) that receives in-kernel cycle stamps; NULL = off (default) */
+void uig_debug_set_strip_stamps(void* dev_buf);
 
 /* aten::convolution / aten::convolution_backward(input grad) — implicit GEMM, LDS-staged im2col tiles -> MFMA.
  *   y[b, oh, ow, n] = act( bias[n] + sum_{tap,c} x[b, ih(tap), iw(tap), c] * wp[n][tap][c] )

@@ -11,11 +11,13 @@ ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--only", default="")
 ap.add_argument("--tile", type=int, default=0)
+ap.add_argument("--strip", type=int, default=1)
 args = ap.parse_args()
 dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 dev = "cuda"
 L = u.lib
 L.lib().uig_debug_set_tile(args.tile)
+L.lib().uig_debug_set_strip(args.strip)
 
 
 def timeit(fn, iters=args.iters):

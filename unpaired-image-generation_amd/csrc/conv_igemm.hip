@@ -14,6 +14,7 @@
 // consecutive output channels of one pixel (8/16-byte stores into NHWC).
 // Reflection padding is resolved in the gather address map; zero padding and ragged tiles by the buffer range check.
 #include "uig_common.h"
+#include <algorithm>
 
 struct GatherDesc {
     int B, H, W, Cin;
@@ -227,17 +228,38 @@ void igemm_kernel(const T* __restrict__ x, const T* __restrict__ wp, const float
         }
     }
 
-    // ---- epilogue: lane holds channels n..n+3 (rows 4q+reg of the 16x16 tile) of pixel column l16
+    // ---- epilogue: full-row stores through LDS when this wave's 64 channels are all stored, else direct 8/16-byte stores
     const int oh0 = d.ph_oh[ph], ow0 = d.ph_ow[ph];
     const bool vec_ok = ((d.Nstore & 3) == 0) && ((d.ldc & 3) == 0);
-#pragma unroll
-    for (int b = 0; b < MT; ++b) {
-        const int m = m_base + wm * WM + b * 16 + l16;
-        if (m >= M) continue;
+    const int nw0 = n_base + wn * WN;
+    auto out_row = [&](int m) -> T* {                 // output pointer (channel 0) of GEMM row m, nullptr if not stored
+        if (m >= M) return nullptr;
         const int jj = m % d.Mw, t = m / d.Mw, ii = t % d.Mh, bb = t / d.Mh;
         const int ho = ii * d.so + oh0, wo = jj * d.so + ow0;
-        if (ho >= d.Ho || wo >= d.Wo) continue;
-        T* yp = y + ((long)(bb * d.Ho + ho) * d.Wo + wo) * d.ldc;
+        if (ho >= d.Ho || wo >= d.Wo) return nullptr;
+        return y + ((long)(bb * d.Ho + ho) * d.Wo + wo) * d.ldc;
+    };
+    if constexpr (MT == 4 && NT == 4) {
+        __syncthreads();                                   // block-uniform: every wave is done reading the staging buffers
+        if (vec_ok && nw0 + 64 <= d.Nstore && (d.ldc * (int)sizeof(T)) % 16 == 0) {      // wave-uniform choice
+            float b4[NT * 4];
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = nw0 + a * 16 + 4 * q + e;
+                    b4[a * 4 + e] = (bias != nullptr && n < d.Nrows) ? bias[n] : 0.f;
+                }
+            const int mw = m_base + wm * WM;
+            store_tile_via_lds<T, MT, NT>(acc, smem + wave * (64 * 64 * (int)sizeof(T)), lane, b4, d.act, d.slope,
+                                          [&](int r) -> T* { T* pp = out_row(mw + r); return pp ? pp + nw0 : nullptr; });
+            return;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+        T* yp = out_row(m_base + wm * WM + b * 16 + l16);
+        if (yp == nullptr) continue;
 #pragma unroll
         for (int a = 0; a < NT; ++a) {
             const int n = n_base + wn * WN + a * 16 + 4 * q;
@@ -317,6 +339,10 @@ static int dispatch_igemm(const void* x, const void* wp, const float* bias, void
                  : launch_igemm<T, 128, 128, 2, 2, 2, false>(x, wp, bias, y, d, s);
 }
 
+int uig_try_conv_strip(const void* x, const void* wp, const float* bias, void* y, int B, int H, int W, int Cin, int Nrows,
+                       int k, int pad_mode, const int* taps, int ntaps, int dh_min, int dh_max, int Ho, int Wo, int ldc, int Nstore,
+                       int act, float slope, int dtype, long x_bytes, long w_bytes, hipStream_t s, int* rc_out);
+
 static int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
 extern "C" int uig_conv_gather(const void* x, const void* wp, const float* bias, void* y,
@@ -379,5 +405,12 @@ extern "C" int uig_conv_gather(const void* x, const void* wp, const float* bias,
             UIG_CHECK_ARG(d.ph_tap0[p + 1] > d.ph_tap0[p], "uig_conv_gather: transposed phase %d has no taps (k=%dx%d s=%d p=%d)", p, kH, kW, stride, pad);
     }
     hipStream_t s = (hipStream_t)stream;
+    if (d.nphase == 1 && stride == 1 && kH == kW) {      // stride-1 k x k: LDS-resident input strip kernel (conv_strip.hip)
+        int dmin = 127, dmax = -127, rc = 0;
+        for (int t = 0; t < kH * kW; ++t) { const int dh = (d.tap[t] & 255) - 128; dmin = std::min(dmin, dh); dmax = std::max(dmax, dh); }
+        if (uig_try_conv_strip(x, wp, bias, y, B, H, W, Cin, Nrows, kH, pad_mode, d.tap, kH * kW, dmin, dmax, Ho, Wo, ldc, Nstore,
+                               act, slope, dtype, (long)d.x_bytes, (long)d.w_bytes, s, &rc))
+            return rc;
+    }
     return dtype == UIG_BF16 ? dispatch_igemm<bf16_t>(x, wp, bias, y, d, s) : dispatch_igemm<float>(x, wp, bias, y, d, s);
 }

@@ -73,6 +73,53 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Output-tile store through LDS for the MFMA conv kernels.  After the MFMAs a lane holds 4 consecutive channels of one
+// pixel per 16x16 tile; storing those directly is 16 scattered 8-byte stores per lane (measured: 26 % of the kernel).
+// Instead each wave writes its 64-pixel x 64-channel tile (bias + activation applied, converted to T) into its own LDS
+// scratch as [pixel][channel] rows with a 16-byte-chunk XOR swizzle, then reads it back row-wise so that consecutive
+// lanes hold consecutive 16-byte chunks of one pixel and every store instruction writes whole 128/256-byte rows.
+// row_ptr(r) returns the output pointer of tile row r (pixel) at channel 0 of this wave's 64 channels, or nullptr.
+template <typename T, int MT, int NT, typename RowPtr>
+__device__ __forceinline__ void store_tile_via_lds(const f32x4_t (&acc)[NT][MT], unsigned char* scratch, int lane,
+                                                   const float* bias4 /* NT*4 bias values of this lane, or nullptr */,
+                                                   int act, float slope, RowPtr row_ptr) {
+    static_assert(MT == 4 && NT == 4, "64 x 64 wave tile");
+    constexpr int ROWB = 64 * (int)sizeof(T);          // 128 (bf16) / 256 (f32) bytes per pixel row
+    constexpr int NCH = ROWB / 16;                     // 16-byte chunks per row
+    const int l16 = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+        const int m = b * 16 + l16;
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[a][b][e] + (bias4 ? bias4[a * 4 + e] : 0.f), act, slope);
+            if constexpr (sizeof(T) == 4) {
+                const int chunk = (4 * a + q) ^ (m & (NCH - 1));
+                *reinterpret_cast<f32x4_t*>(scratch + m * ROWB + chunk * 16) = f32x4_t{v[0], v[1], v[2], v[3]};
+            } else {
+                const int chunk = (2 * a + (q >> 1)) ^ (m & (NCH - 1));
+                u32x2_t pk;
+                pk[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                pk[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                *reinterpret_cast<u32x2_t*>(scratch + m * ROWB + chunk * 16 + (q & 1) * 8) = pk;
+            }
+        }
+    }
+    // the scratch is private to the wave: only its own LDS writes must have landed (the compiler inserts lgkmcnt waits)
+    constexpr int RPI = 64 / NCH;                      // rows per store instruction (8 for bf16, 4 for f32)
+    const int c = lane % NCH, r0 = lane / NCH;
+#pragma unroll
+    for (int i = 0; i < 64 / RPI; ++i) {
+        const int r = r0 + RPI * i;
+        T* dst = row_ptr(r);
+        const u32x4_t val = *reinterpret_cast<const u32x4_t*>(scratch + r * ROWB + ((c ^ (r & (NCH - 1))) * 16));
+        if (dst != nullptr) *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(dst) + c * 16) = val;
+    }
+}
+
 // host-side error plumbing (defined in uig_capi.hip)
 int uig_set_error(int code, const char* fmt, ...);
 #define UIG_CHECK_ARG(cond, ...) do { if (!(cond)) return uig_set_error(-1, __VA_ARGS__); } while (0)
