@@ -7,10 +7,24 @@ streams and autograd bookkeeping only; every FLOP on these paths runs in libuig.
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
 from torch.autograd import Function
 
 from . import lib as L
+
+
+PARALLEL_BACKWARD = True      # run a conv's parameter-gradient kernels concurrently with its input-gradient kernel
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device) -> torch.cuda.Stream:
+    key = torch.device(device).index
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -239,8 +253,28 @@ class ConvFn(Function):
             dy = g
         dy = _dy_padded(spec, dy)
         dx = dW = db = None
-        if ctx.needs_input_grad[0]:
+        # The input gradient and the parameter gradients are independent given dy: fork the parameter-gradient kernels
+        # onto a side stream and join before returning.  The input-gradient grid rarely fills a whole number of rounds
+        # on 256 CUs (e.g. 288 tiles), and the weight-gradient blocks soak up the idle CUs of its tail.  Safe for the
+        # caching allocator (and capturable into a HIP graph): the join orders every later use of dy / x after the fork.
+        need_par = ctx.needs_input_grad[0] and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and PARALLEL_BACKWARD
+        main = torch.cuda.current_stream(dy.device)
+        side = _side_stream(dy.device) if need_par else None
+        if ctx.needs_input_grad[0] and not need_par:
             dx = conv_dgrad(spec, dy, layer.wp_dgrad, ctx.in_hw)
+        if need_par:
+            side.wait_stream(main)
+        pctx = torch.cuda.stream(side) if need_par else contextlib.nullcontext()
+        with pctx:
+            dW, db = ConvFn._param_grads(ctx, layer, spec, x, dy)
+        if need_par:
+            dx = conv_dgrad(spec, dy, layer.wp_dgrad, ctx.in_hw)
+            main.wait_stream(side)
+        return dx, dW, db, None
+
+    @staticmethod
+    def _param_grads(ctx, layer, spec, x, dy):
+        dW = db = None
         # Parameter gradients: when the parameter already owns a .grad buffer (the trainer's flat gradient buffer, or any
         # earlier backward) the reduce kernels ADD into it in place and autograd gets None (= nothing more to accumulate):
         # gradient-accumulation fusion, no temporary dW and no extra add kernel.  Otherwise return them the usual way.
@@ -256,7 +290,7 @@ class ConvFn(Function):
                 bias_grad(dy, spec.cout, out=b.grad, accumulate=True)
             else:
                 db = bias_grad(dy, spec.cout)
-        return dx, dW, db, None
+        return dW, db
 
 
 # ----------------------------------------------------------------------------------------- instance norm (+act, +residual)
