@@ -17,6 +17,7 @@ struct WgradDesc {
     int kW, taps, stride, pad, pad_mode;
     int ncols;               // taps * Cq
     int M, Mper;             // pixels total, pixels per split (multiple of 32)
+    unsigned p_bytes, q_bytes;
 };
 
 template <typename T> struct WgTraits;
@@ -66,27 +67,44 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const T* __restrict__ P, 
     }
 
     u32x4_t rq[QI], rp[PI];
+    // buffer descriptors: invalid rows / zero padding use an out-of-range offset (hardware returns zeros)
+    const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Q), 0, d.q_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(P), 0, d.p_bytes, 0x00020000);
+    // running pixel coordinates (b, i, j) of each Q row of the K-step being loaded: one division at the start, then
+    // incremental updates (the per-K-step divisions made this loop VALU-bound: ~250 VALU per 16 MFMAs)
+    int qj[QI], qi[QI], qb[QI];
+#pragma unroll
+    for (int i = 0; i < QI; ++i) {
+        const int m = m_begin + q_row[i];
+        qj[i] = m % d.Mw; const int t = m / d.Mw; qi[i] = t % d.Mh; qb[i] = t / d.Mh;
+    }
+    const bool refl = d.pad_mode == UIG_PAD_REFLECT;
     auto load_tile = [&](int ks) {
         const int mk = m_begin + ks * BKP;
 #pragma unroll
         for (int i = 0; i < QI; ++i) {
             const int m = mk + q_row[i];
-            bool ok = q_ok[i] && (m < m_end);
-            const int mm = ok ? m : 0;
-            const int jj = mm % d.Mw, t = mm / d.Mw, ii = t % d.Mh, b = t / d.Mh;
-            int hi = ii * d.stride + q_dh[i], wi = jj * d.stride + q_dw[i];
-            if (d.pad_mode == UIG_PAD_REFLECT) { hi = reflect_idx(hi, d.Hq); wi = reflect_idx(wi, d.Wq); }
-            else ok = ok && ((unsigned)hi < (unsigned)d.Hq) && ((unsigned)wi < (unsigned)d.Wq);
-            const long off = ((long)((b * d.Hq + hi) * d.Wq + wi)) * d.Cq + q_c[i];
-            u32x4_t z = {0u, 0u, 0u, 0u};
-            rq[i] = ok ? *reinterpret_cast<const u32x4_t*>(Q + off) : z;
+            const int hi = qi[i] * d.stride + q_dh[i], wi = qj[i] * d.stride + q_dw[i];
+            const bool inb = ((unsigned)hi < (unsigned)d.Hq) & ((unsigned)wi < (unsigned)d.Wq);
+            const bool ok = q_ok[i] & (m < m_end) & (refl | inb);
+            const int hr = refl ? reflect_idx(hi, d.Hq) : hi, wr = refl ? reflect_idx(wi, d.Wq) : wi;
+            const unsigned off = ok ? (unsigned)((((qb[i] * d.Hq + hr) * d.Wq + wr) * d.Cq + q_c[i]) * (int)sizeof(T)) : 0xFFFFFFFFu;
+            rq[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsq, (int)off, 0, 0));
+            // advance this row by BKP pixels for the next call
+            if (d.Mw >= BKP) {
+                qj[i] += BKP;
+                if (qj[i] >= d.Mw) { qj[i] -= d.Mw; if (++qi[i] == d.Mh) { qi[i] = 0; ++qb[i]; } }
+            } else {
+                const int mn = m + BKP;
+                qj[i] = mn % d.Mw; const int t = mn / d.Mw; qi[i] = t % d.Mh; qb[i] = t / d.Mh;
+            }
         }
 #pragma unroll
         for (int i = 0; i < PI; ++i) {
             const int m = mk + p_row[i];
-            const bool ok = p_ok[i] && (m < m_end);
-            u32x4_t z = {0u, 0u, 0u, 0u};
-            rp[i] = ok ? *reinterpret_cast<const u32x4_t*>(P + (long)m * d.Np + p_n[i]) : z;
+            const bool ok = p_ok[i] & (m < m_end);
+            const unsigned off = ok ? (unsigned)((m * d.Np + p_n[i]) * (int)sizeof(T)) : 0xFFFFFFFFu;
+            rp[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsp, (int)off, 0, 0));
         }
     };
     auto store_tile = [&](int stage) {
@@ -229,7 +247,7 @@ extern "C" int uig_wgrad_partial(const void* P, const void* Q, float* workspace,
     UIG_CHECK_ARG(splits >= 1 && splits <= 65535, "uig_wgrad_partial: bad splits %d", splits);
     UIG_CHECK_ARG(stride == 1 || stride == 2, "uig_wgrad_partial: stride=%d unsupported", stride);
     UIG_CHECK_ARG(dtype == UIG_F32 || dtype == UIG_BF16, "uig_wgrad_partial: bad dtype %d", dtype);
-    UIG_CHECK_ARG((long)B * Mh * Mw * Np < (1L << 31) && (long)B * Hq * Wq * Cq < (1L << 31), "uig_wgrad_partial: tensor too large");
+    UIG_CHECK_ARG((long)B * Mh * Mw * Np * (dtype == UIG_BF16 ? 2 : 4) < (1L << 32) - 64 && (long)B * Hq * Wq * Cq * (dtype == UIG_BF16 ? 2 : 4) < (1L << 32) - 64, "uig_wgrad_partial: tensor too large for 32-bit byte offsets");
     if (pad_mode == UIG_PAD_REFLECT) {
         UIG_CHECK_ARG(pad < Hq && pad < Wq, "uig_wgrad_partial: reflect pad %d >= dim", pad);
     }
@@ -241,6 +259,8 @@ extern "C" int uig_wgrad_partial(const void* P, const void* Q, float* workspace,
     d.kW = kW; d.taps = kH * kW; d.stride = stride; d.pad = pad; d.pad_mode = pad_mode;
     d.ncols = kH * kW * Cq; d.M = B * Mh * Mw;
     d.Mper = ((d.M + splits - 1) / splits + 31) / 32 * 32;
+    const long esz = dtype == UIG_BF16 ? 2 : 4;
+    d.p_bytes = (unsigned)((long)B * Mh * Mw * Np * esz); d.q_bytes = (unsigned)((long)B * Hq * Wq * Cq * esz);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == UIG_BF16)
         return Np <= 16 ? launch_wgrad<bf16_t, 16>(P, Q, workspace, d, splits, s) : launch_wgrad<bf16_t, 128>(P, Q, workspace, d, splits, s);
