@@ -28,7 +28,8 @@ template <typename T, int BN>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const T* __restrict__ P, const T* __restrict__ Q,
                                                         float* __restrict__ part, const WgradDesc d) {
     constexpr int E = ElemTraits<T>::E;
-    constexpr int BC = 128, BKP = 32;
+    constexpr int BC = 128;
+    constexpr int BKP = (sizeof(T) == 2) ? 64 : 32;   // pixels per K-step: bf16 64 (two MFMA k-groups per barrier), f32 32
     constexpr int WAVES_N = (BN >= 128) ? 2 : 1, WAVES_C = 4 / WAVES_N;
     constexpr int WN = BN / WAVES_N, WC = BC / WAVES_C, NT = WN / 16, CT = WC / 16;
     constexpr int PROW = BN * (int)sizeof(T) + WgTraits<T>::PAD;      // LDS row strides (bytes)
@@ -145,26 +146,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const T* __restrict__ P, 
             // bf16: transpose reads. lane 4q+p of a 16-lane group addresses pixel row (4g+q [+16]), channels 4p..4p+3;
             // it receives channel l16 of those 4 pixel rows. fragment k order: {4g..4g+3, 16+4g..16+4g+3} for both operands.
             const int qq = l16 >> 2, pp = l16 & 3;
-            bf16x8_t af[CT], bf[NT];
 #pragma unroll
-            for (int a = 0; a < CT; ++a) {
-                const unsigned char* base = sq + (4 * g + qq) * QROW + (wc * WC + a * 16 + 4 * pp) * 2;
-                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(base));
-                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(base + 16 * QROW));
-                af[a] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            for (int kg = 0; kg < BKP / 32; ++kg) {
+                bf16x8_t af[CT], bf[NT];
+#pragma unroll
+                for (int a = 0; a < CT; ++a) {
+                    const unsigned char* base = sq + (32 * kg + 4 * g + qq) * QROW + (wc * WC + a * 16 + 4 * pp) * 2;
+                    bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(base));
+                    bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(base + 16 * QROW));
+                    af[a] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    const unsigned char* base = sp + (32 * kg + 4 * g + qq) * PROW + (wn * WN + b * 16 + 4 * pp) * 2;
+                    bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(base));
+                    bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(base + 16 * PROW));
+                    bf[b] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int a = 0; a < CT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
             }
-#pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                const unsigned char* base = sp + (4 * g + qq) * PROW + (wn * WN + b * 16 + 4 * pp) * 2;
-                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(base));
-                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(base + 16 * PROW));
-                bf[b] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
-#pragma unroll
-            for (int a = 0; a < CT; ++a)
-#pragma unroll
-                for (int b = 0; b < NT; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
         } else {
             // f32: A[i = l16][k = g] per 16x16x4 step; pixel row = 4*kk + g
 #pragma unroll
@@ -225,7 +229,7 @@ extern "C" size_t uig_wgrad_workspace_bytes(int Np, int Cq, int kH, int kW, int 
 template <typename T, int BN>
 static int launch_wgrad(const void* P, const void* Q, float* ws, const WgradDesc& d, int splits, hipStream_t s) {
     constexpr int PROW = BN * (int)sizeof(T) + WgTraits<T>::PAD, QROW = 128 * (int)sizeof(T) + WgTraits<T>::PAD;
-    const size_t smem = 2 * 32 * (size_t)(PROW + QROW);
+    const size_t smem = 2 * (size_t)(sizeof(T) == 2 ? 64 : 32) * (size_t)(PROW + QROW);
     auto kern = wgrad_kernel<T, BN>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -258,7 +262,7 @@ extern "C" int uig_wgrad_partial(const void* P, const void* Q, float* workspace,
     d.B = B; d.Mh = Mh; d.Mw = Mw; d.Np = Np; d.Hq = Hq; d.Wq = Wq; d.Cq = Cq;
     d.kW = kW; d.taps = kH * kW; d.stride = stride; d.pad = pad; d.pad_mode = pad_mode;
     d.ncols = kH * kW * Cq; d.M = B * Mh * Mw;
-    d.Mper = ((d.M + splits - 1) / splits + 31) / 32 * 32;
+    d.Mper = ((d.M + splits - 1) / splits + 63) / 64 * 64;
     const long esz = dtype == UIG_BF16 ? 2 : 4;
     d.p_bytes = (unsigned)((long)B * Mh * Mw * Np * esz); d.q_bytes = (unsigned)((long)B * Hq * Wq * Cq * esz);
     hipStream_t s = (hipStream_t)stream;
