@@ -54,6 +54,14 @@ int uig_conv_gather(const void* x, const void* wp, const float* bias, void* y,
                     int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
                     int act, float slope, int dtype, void* stream);
 
+/* Paired launch: the same convolution for TWO networks of identical architecture in one grid (CycleGAN's G_A/G_B and
+ * D_A/D_B always process same-shaped batches).  Images b < group_images use (wp, bias), the others (wp2, bias2). */
+int uig_conv_gather_pair(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2,
+                         int group_images, void* y,
+                         int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
+                         int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
+                         int act, float slope, int dtype, void* stream);
+
 /* aten::convolution_backward(weight grad) — dW partials by split-K MFMA GEMM over pixels, then uig_wgrad_reduce.
  *   part[s][n][tap][c] = sum_{pixels m in split s} P[m][n] * Q[pix(m,tap)][c]
  * P: dense operand (B,Mh,Mw,Np) (dy for Conv2d, x for ConvTranspose2d); Q: gathered operand (B,Hq,Wq,Cq) read at

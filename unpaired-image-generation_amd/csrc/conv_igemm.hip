@@ -30,6 +30,9 @@ struct GatherDesc {
     int ph_tap0[5];
     signed char ph_oh[4], ph_ow[4];
     int tap[64];           // per tap: (dh + 128) | (dw + 128) << 8 | weight-tap-index << 16  (one scalar dword load)
+    const void* wp2;       // paired launch: GEMM rows >= group_rows (the second network's images) use wp2 / bias2
+    const float* bias2;
+    int group_rows;
 };
 
 template <typename T> struct Mma;
@@ -52,7 +55,7 @@ template <> struct Mma<float> {
 //              (no implicit drain) orders it for the other waves' ds_reads: the LDS-DMA stream never stops.
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, bool SMALL_CIN>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2)
-void igemm_kernel(const T* __restrict__ x, const T* __restrict__ wp, const float* __restrict__ bias, T* __restrict__ y,
+void igemm_kernel(const T* __restrict__ x, const T* __restrict__ wp_, const float* __restrict__ bias_, T* __restrict__ y,
                   const GatherDesc d) {
     constexpr int E = ElemTraits<T>::E;
     constexpr int BK = 8 * E;                 // 128 bytes of K per row per step
@@ -78,6 +81,9 @@ void igemm_kernel(const T* __restrict__ x, const T* __restrict__ wp, const float
     }
     const int ntn = (d.Nrows + BN - 1) / BN;
     const int n_base = (bid % ntn) * BN, m_base = (bid / ntn) * BM;
+    const bool g2 = d.wp2 != nullptr && m_base >= d.group_rows;        // block-uniform: tiles never straddle the groups
+    const T* wp = g2 ? static_cast<const T*>(d.wp2) : wp_;
+    const float* bias = g2 ? d.bias2 : bias_;
     const int ph = blockIdx.y;
     const int tap0 = d.ph_tap0[ph], ntap = d.ph_tap0[ph + 1] - tap0;
     const int M = d.B * d.Mh * d.Mw;
@@ -339,17 +345,19 @@ static int dispatch_igemm(const void* x, const void* wp, const float* bias, void
                  : launch_igemm<T, 128, 128, 2, 2, 2, false>(x, wp, bias, y, d, s);
 }
 
-int uig_try_conv_strip(const void* x, const void* wp, const float* bias, void* y, int B, int H, int W, int Cin, int Nrows,
+int uig_try_conv_strip(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
+                       void* y, int B, int H, int W, int Cin, int Nrows,
                        int k, int pad_mode, const int* taps, int ntaps, int dh_min, int dh_max, int Ho, int Wo, int ldc, int Nstore,
                        int act, float slope, int dtype, long x_bytes, long w_bytes, hipStream_t s, int* rc_out);
 
 static int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
-extern "C" int uig_conv_gather(const void* x, const void* wp, const float* bias, void* y,
-                               int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
-                               int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
-                               int act, float slope, int dtype, void* stream) {
+static int conv_gather_impl(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
+                            void* y, int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
+                            int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
+                            int act, float slope, int dtype, void* stream) {
     UIG_CHECK_ARG(x && wp && y, "uig_conv_gather: null pointer");
+    if (wp2 != nullptr) UIG_CHECK_ARG(group_images > 0 && group_images < B, "uig_conv_gather_pair: group_images=%d must be in (0, B=%d)", group_images, B);
     UIG_CHECK_ARG(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "uig_conv_gather: bad shape B=%d H=%d W=%d Ho=%d Wo=%d", B, H, W, Ho, Wo);
     UIG_CHECK_ARG(Cin >= 8 && Cin % 8 == 0, "uig_conv_gather: Cin=%d must be a multiple of 8 (pad channels)", Cin);
     UIG_CHECK_ARG(kH >= 1 && kW >= 1 && kH * kW <= 64 && kH <= 8 && kW <= 8, "uig_conv_gather: unsupported kernel %dx%d", kH, kW);
@@ -408,9 +416,40 @@ extern "C" int uig_conv_gather(const void* x, const void* wp, const float* bias,
     if (d.nphase == 1 && stride == 1 && kH == kW) {      // stride-1 k x k: LDS-resident input strip kernel (conv_strip.hip)
         int dmin = 127, dmax = -127, rc = 0;
         for (int t = 0; t < kH * kW; ++t) { const int dh = (d.tap[t] & 255) - 128; dmin = std::min(dmin, dh); dmax = std::max(dmax, dh); }
-        if (uig_try_conv_strip(x, wp, bias, y, B, H, W, Cin, Nrows, kH, pad_mode, d.tap, kH * kW, dmin, dmax, Ho, Wo, ldc, Nstore,
-                               act, slope, dtype, (long)d.x_bytes, (long)d.w_bytes, s, &rc))
+        if (uig_try_conv_strip(x, wp, bias, wp2, bias2, group_images, y, B, H, W, Cin, Nrows, kH, pad_mode, d.tap, kH * kW, dmin, dmax,
+                               Ho, Wo, ldc, Nstore, act, slope, dtype, (long)d.x_bytes, (long)d.w_bytes, s, &rc))
             return rc;
     }
+    if (wp2 != nullptr) {
+        const long grows = (long)group_images * d.Mh * d.Mw;
+        if (grows % 256 != 0) {      // a tile could straddle the two groups: run them as two launches (same results)
+            const long esz2 = dtype == UIG_BF16 ? 2 : 4;
+            int rc = conv_gather_impl(x, wp, bias, nullptr, nullptr, 0, y, group_images, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode,
+                                      gather_mode, Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
+            if (rc) return rc;
+            return conv_gather_impl((const char*)x + (long)group_images * H * W * Cin * esz2, wp2, bias2, nullptr, nullptr, 0,
+                                    (char*)y + (long)group_images * Ho * Wo * ldc * esz2, B - group_images, H, W, Cin, Nrows, kH, kW,
+                                    stride, pad, pad_mode, gather_mode, Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
+        }
+        d.wp2 = wp2; d.bias2 = bias2; d.group_rows = (int)grows;
+    }
     return dtype == UIG_BF16 ? dispatch_igemm<bf16_t>(x, wp, bias, y, d, s) : dispatch_igemm<float>(x, wp, bias, y, d, s);
+}
+
+extern "C" int uig_conv_gather(const void* x, const void* wp, const float* bias, void* y,
+                               int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
+                               int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
+                               int act, float slope, int dtype, void* stream) {
+    return conv_gather_impl(x, wp, bias, nullptr, nullptr, 0, y, B, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode, gather_mode,
+                            Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
+}
+
+extern "C" int uig_conv_gather_pair(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2,
+                                    int group_images, void* y,
+                                    int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
+                                    int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
+                                    int act, float slope, int dtype, void* stream) {
+    UIG_CHECK_ARG(wp2 != nullptr, "uig_conv_gather_pair: null wp2");
+    return conv_gather_impl(x, wp, bias, wp2, bias2, group_images, y, B, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode, gather_mode,
+                            Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
 }

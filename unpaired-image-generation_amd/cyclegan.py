@@ -20,14 +20,15 @@ import torch
 
 from . import ops
 from .dp import FlatGroup, GradExchange
-from .networks import Discriminator, Generator
+from .networks import Discriminator, Generator, pair_forward_phys
 
 LOSS_NAMES = ("idt_A", "idt_B", "G_A", "G_B", "cyc_A", "cyc_B", "D_A", "D_B")
 
 
 class CycleGAN:
     def __init__(self, n_blocks=9, dtype=torch.bfloat16, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-8,
-                 lambda_cyc=10.0, lambda_idt=0.5, device="cuda", process_group=None, use_graph=False, batch_fused=True, force_exchange=False):
+                 lambda_cyc=10.0, lambda_idt=0.5, device="cuda", process_group=None, use_graph=False, batch_fused=True, paired=True,
+                 force_exchange=False):
         self.device, self.dtype = torch.device(device), dtype
         kw = dict(dtype=dtype, device=device)
         self.G_A, self.G_B = Generator(n_blocks=n_blocks, **kw), Generator(n_blocks=n_blocks, **kw)
@@ -36,7 +37,7 @@ class CycleGAN:
         self.lam, self.lam_idt = lambda_cyc, lambda_idt
         self.xchg = GradExchange(process_group, force=force_exchange)
         self.world = self.xchg.world
-        self.use_graph, self.batch_fused = use_graph, batch_fused
+        self.use_graph, self.batch_fused, self.paired = use_graph, batch_fused, paired
         self._graphs = None
         self._finalize_params()
 
@@ -76,20 +77,30 @@ class CycleGAN:
         B = xa.shape[0]
         self.grp_D.set_requires_grad(False)
         self.grp_G.zero_grad()
-        if self.batch_fused:
+        if self.batch_fused and self.paired:
+            # G_A on [xa; xb] and G_B on [xb; xa] as ONE paired pass over 4B images, then G_B(fake_B) / G_A(fake_A) as one
+            o = pair_forward_phys(self.G_A, self.G_B, torch.cat([xa, xb, xb, xa]))
+            fake_B, idt_A, fake_A, idt_B = o[:B], o[B:2 * B], o[2 * B:3 * B], o[3 * B:]
+            r = pair_forward_phys(self.G_B, self.G_A, torch.cat([fake_B, fake_A]))
+            rec_A, rec_B = r[:B], r[B:]
+        elif self.batch_fused:
             oa = self.G_A.forward_phys(torch.cat([xa, xb]))      # [fake_B ; idt_A]
             ob = self.G_B.forward_phys(torch.cat([xb, xa]))      # [fake_A ; idt_B]
             fake_B, idt_A, fake_A, idt_B = oa[:B], oa[B:], ob[:B], ob[B:]
+            rec_A, rec_B = self.G_B.forward_phys(fake_B), self.G_A.forward_phys(fake_A)
         else:
             fake_B, fake_A = self.G_A.forward_phys(xa), self.G_B.forward_phys(xb)
             idt_A, idt_B = self.G_A.forward_phys(xb), self.G_B.forward_phys(xa)
-        rec_A = self.G_B.forward_phys(fake_B)
-        rec_B = self.G_A.forward_phys(fake_A)
+            rec_A, rec_B = self.G_B.forward_phys(fake_B), self.G_A.forward_phys(fake_A)
         n_real = B * xa.shape[1] * xa.shape[2] * 3
         l_idt_A = ops.l1_loss(idt_A, xb, self.lam * self.lam_idt, n_real)
         l_idt_B = ops.l1_loss(idt_B, xa, self.lam * self.lam_idt, n_real)
-        l_G_A = ops.mse_const(self.D_A.forward_phys(fake_B), 1.0)
-        l_G_B = ops.mse_const(self.D_B.forward_phys(fake_A), 1.0)
+        if self.batch_fused and self.paired:
+            pd = pair_forward_phys(self.D_A, self.D_B, torch.cat([fake_B, fake_A]))
+            l_G_A, l_G_B = ops.mse_const(pd[:B], 1.0), ops.mse_const(pd[B:], 1.0)
+        else:
+            l_G_A = ops.mse_const(self.D_A.forward_phys(fake_B), 1.0)
+            l_G_B = ops.mse_const(self.D_B.forward_phys(fake_A), 1.0)
         l_cyc_A = ops.l1_loss(rec_A, xa, self.lam, n_real)
         l_cyc_B = ops.l1_loss(rec_B, xb, self.lam, n_real)
         losses = [l_idt_A, l_idt_B, l_G_A, l_G_B, l_cyc_A, l_cyc_B]
@@ -102,6 +113,12 @@ class CycleGAN:
         self.grp_D.zero_grad()
         B = xa.shape[0]
         out = []
+        if self.batch_fused and self.paired:      # D_A on [real_B; fake_B] and D_B on [real_A; fake_A] as one paired pass
+            p = pair_forward_phys(self.D_A, self.D_B, torch.cat([xb, fake_B, xa, fake_A]))
+            ls = [ops.mse_const(p[:B], 1.0, 0.5), ops.mse_const(p[B:2 * B], 0.0, 0.5),
+                  ops.mse_const(p[2 * B:3 * B], 1.0, 0.5), ops.mse_const(p[3 * B:], 0.0, 0.5)]
+            torch.autograd.backward(ls)
+            return [(ls[0], ls[1]), (ls[2], ls[3])]
         for D, real, fake in ((self.D_A, xb, fake_B), (self.D_B, xa, fake_A)):
             if self.batch_fused:
                 p = D.forward_phys(torch.cat([real, fake]))

@@ -51,9 +51,12 @@ class ConvLayer(nn.Module):
         ops.pack_weights(self.spec, self.weight.data, self.compute_dtype, self.wp_fwd, self.wp_dgrad)
         self._packed_version = self.weight._version
 
-    def forward(self, x):
+    def ensure_packed(self):
         if self._packed_version != self.weight._version:
             self.repack()
+
+    def forward(self, x):
+        self.ensure_packed()
         return ops.ConvFn.apply(x, self.weight, self.bias, self)
 
     def extra_repr(self):
@@ -151,3 +154,28 @@ class Discriminator(_PhysNet):
         mods += [ConvLayer("conv", ndf * nf, 1, 4, 1, 1, **kw)]
         super().__init__(*mods)
         self.in_ch, self.out_ch, self.compute_dtype = in_ch, 1, dtype
+
+
+def pair_forward_phys(net1: _PhysNet, net2: _PhysNet, x: torch.Tensor) -> torch.Tensor:
+    """Run two networks of identical architecture in lockstep on one stacked batch: the first half of x goes through net1,
+    the second half through net2, every convolution as ONE paired launch (ops.PairConvFn); InstanceNorm / activations are
+    per-sample and simply see the whole batch.  Numerically identical to net1(x[:h]) and net2(x[h:])."""
+    if x.shape[0] % 2:
+        raise ValueError("pair_forward_phys: the stacked batch must be even")
+    g = x.shape[0] // 2
+
+    def conv(l1, l2, t):
+        if l1.spec.__dict__ != l2.spec.__dict__:
+            raise ValueError("pair_forward_phys: the two networks differ")
+        l1.ensure_packed(); l2.ensure_packed()
+        return ops.PairConvFn.apply(t, l1.weight, l1.bias, l2.weight, l2.bias, l1, l2, g)
+
+    for m1, m2 in zip(net1, net2):
+        if isinstance(m1, ConvLayer):
+            x = conv(m1, m2, x)
+        elif isinstance(m1, ResBlock):
+            h = m1.b[2](conv(m1.b[1], m2.b[1], x))
+            x = m1.b[6](conv(m1.b[5], m2.b[5], h), residual=x)
+        else:                      # InstNormAct / _Slot: no parameters, per-sample
+            x = m1(x)
+    return x

@@ -136,7 +136,20 @@ def packed_shapes(spec: ConvSpec):
     return (spec.cout, t, spec.cin_p), (spec.cin, t, spec.cout_p)
 
 
-def conv_forward(spec: ConvSpec, x: torch.Tensor, wp_fwd: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
+def _gather(x, wp, bias, y, B, H, W, C, nrows, spec, stride, pad, pm, mode, Ho, Wo, ldc, act, slope, what, pair=None):
+    """one uig_conv_gather launch; pair = (wp2, bias2, group_images) makes it a two-network launch"""
+    lib = L.lib()
+    if pair is None:
+        rc = lib.uig_conv_gather(_p(x), _p(wp), _p(bias), _p(y), B, H, W, C, nrows, spec.k, spec.k, stride, pad, pm, mode,
+                                 Ho, Wo, ldc, ldc, act, slope, _dt(x), _stream())
+    else:
+        wp2, bias2, g = pair
+        rc = lib.uig_conv_gather_pair(_p(x), _p(wp), _p(bias), _p(wp2), _p(bias2), g, _p(y), B, H, W, C, nrows, spec.k, spec.k,
+                                      stride, pad, pm, mode, Ho, Wo, ldc, ldc, act, slope, _dt(x), _stream())
+    L.check(rc, what)
+
+
+def conv_forward(spec: ConvSpec, x: torch.Tensor, wp_fwd: torch.Tensor, bias: torch.Tensor | None, pair=None) -> torch.Tensor:
     _chk_phys(x, "conv_forward")
     B, H, W, C = x.shape
     if C != spec.cin_p:
@@ -147,9 +160,8 @@ def conv_forward(spec: ConvSpec, x: torch.Tensor, wp_fwd: torch.Tensor, bias: to
         mode, pm = L.GATHER_DIRECT, (L.PAD_REFLECT if spec.reflect else L.PAD_ZERO)
     else:
         mode, pm = L.GATHER_TRANSPOSED, L.PAD_ZERO
-    L.check(L.lib().uig_conv_gather(_p(x), _p(wp_fwd), _p(bias), _p(y), B, H, W, C, spec.cout, spec.k, spec.k,
-                                    spec.stride, spec.pad, pm, mode, Ho, Wo, spec.cout_store, spec.cout_store,
-                                    spec.act, spec.slope, _dt(x), _stream()), "uig_conv_gather(fwd)")
+    _gather(x, wp_fwd, bias, y, B, H, W, C, spec.cout, spec, spec.stride, spec.pad, pm, mode, Ho, Wo, spec.cout_store,
+            spec.act, spec.slope, "uig_conv_gather(fwd)", pair)
     return y
 
 
@@ -161,30 +173,27 @@ def _dy_padded(spec: ConvSpec, dy: torch.Tensor) -> torch.Tensor:
     return to_nhwc(dy.permute(0, 3, 1, 2), dy.dtype, spec.cout_p)
 
 
-def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw) -> torch.Tensor:
-    """aten::convolution_backward, input gradient.  dy: (B,Ho,Wo,cout_p)."""
+def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, pair=None) -> torch.Tensor:
+    """aten::convolution_backward, input gradient.  dy: (B,Ho,Wo,cout_p).  pair = (wp_dgrad2, None, group_images)."""
     B, Ho, Wo, Cd = dy.shape
     H, W = in_hw
-    lib, s = L.lib(), _stream()
+    s = _stream()
     if spec.kind == "convT":     # gradient of a transposed conv = strided direct conv of dy
         dx = torch.empty((B, H, W, spec.cin_p), device=dy.device, dtype=dy.dtype)
-        L.check(lib.uig_conv_gather(_p(dy), _p(wp_dgrad), None, _p(dx), B, Ho, Wo, Cd, spec.cin, spec.k, spec.k, spec.stride,
-                                    spec.pad, L.PAD_ZERO, L.GATHER_DIRECT, H, W, spec.cin_p, spec.cin_p, L.ACT_NONE, 0.0,
-                                    _dt(dy), s), "uig_conv_gather(convT dgrad)")
+        _gather(dy, wp_dgrad, None, dx, B, Ho, Wo, Cd, spec.cin, spec, spec.stride, spec.pad, L.PAD_ZERO, L.GATHER_DIRECT, H, W,
+                spec.cin_p, L.ACT_NONE, 0.0, "uig_conv_gather(convT dgrad)", pair)
         return dx
     if spec.reflect:             # gradient w.r.t. the reflection-padded input, then fold the border back
         P = spec.pad
         dxp = torch.empty((B, H + 2 * P, W + 2 * P, spec.cin_p), device=dy.device, dtype=dy.dtype)
-        L.check(lib.uig_conv_gather(_p(dy), _p(wp_dgrad), None, _p(dxp), B, Ho, Wo, Cd, spec.cin, spec.k, spec.k, spec.stride,
-                                    0, L.PAD_ZERO, L.GATHER_TRANSPOSED, H + 2 * P, W + 2 * P, spec.cin_p, spec.cin_p,
-                                    L.ACT_NONE, 0.0, _dt(dy), s), "uig_conv_gather(dgrad)")
+        _gather(dy, wp_dgrad, None, dxp, B, Ho, Wo, Cd, spec.cin, spec, spec.stride, 0, L.PAD_ZERO, L.GATHER_TRANSPOSED,
+                H + 2 * P, W + 2 * P, spec.cin_p, L.ACT_NONE, 0.0, "uig_conv_gather(dgrad)", pair)
         dx = torch.empty((B, H, W, spec.cin_p), device=dy.device, dtype=dy.dtype)
-        L.check(lib.uig_reflect_fold(_p(dxp), _p(dx), B, H, W, spec.cin_p, P, _dt(dy), s), "uig_reflect_fold")
+        L.check(L.lib().uig_reflect_fold(_p(dxp), _p(dx), B, H, W, spec.cin_p, P, _dt(dy), s), "uig_reflect_fold")
         return dx
     dx = torch.empty((B, H, W, spec.cin_p), device=dy.device, dtype=dy.dtype)
-    L.check(lib.uig_conv_gather(_p(dy), _p(wp_dgrad), None, _p(dx), B, Ho, Wo, Cd, spec.cin, spec.k, spec.k, spec.stride,
-                                spec.pad, L.PAD_ZERO, L.GATHER_TRANSPOSED, H, W, spec.cin_p, spec.cin_p, L.ACT_NONE, 0.0,
-                                _dt(dy), s), "uig_conv_gather(dgrad)")
+    _gather(dy, wp_dgrad, None, dx, B, Ho, Wo, Cd, spec.cin, spec, spec.stride, spec.pad, L.PAD_ZERO, L.GATHER_TRANSPOSED, H, W,
+            spec.cin_p, L.ACT_NONE, 0.0, "uig_conv_gather(dgrad)", pair)
     return dx
 
 
@@ -230,6 +239,68 @@ def bias_grad(dy: torch.Tensor, nreal: int, out: torch.Tensor | None = None, acc
     return out
 
 
+def _param_grads(layer, spec, x, dy, need_w, need_b):
+    """dW / db of one layer.  When the parameter already owns a .grad buffer (the trainer's flat gradient buffer, or any
+    earlier backward) the reduce kernels ADD into it in place and autograd gets None (= nothing more to accumulate):
+    gradient-accumulation fusion, no temporary dW and no extra add kernel.  Otherwise they are returned the usual way."""
+    dW = db = None
+    if need_w:
+        w = layer.weight
+        if layer.fuse_grad_accum and w.grad is not None and w.grad.is_contiguous():
+            conv_wgrad(spec, x, dy, out=w.grad, accumulate=True)
+        else:
+            dW = conv_wgrad(spec, x, dy)
+    if need_b:
+        b = layer.bias
+        if layer.fuse_grad_accum and b.grad is not None and b.grad.is_contiguous():
+            bias_grad(dy, spec.cout, out=b.grad, accumulate=True)
+        else:
+            db = bias_grad(dy, spec.cout)
+    return dW, db
+
+
+def _conv_backward(ctx, dy, layers, group):
+    """Shared backward of ConvFn / PairConvFn.  The input gradient and the parameter gradients are independent given dy:
+    the parameter-gradient kernels are forked onto a side stream and joined before returning.  The input-gradient grid
+    rarely fills a whole number of rounds on 256 CUs (e.g. 288 tiles) and the weight-gradient blocks soak up the idle CUs
+    of its tail.  Safe for the caching allocator (and capturable into a HIP graph): the join orders every later use of
+    dy / x after the fork."""
+    spec = layers[0].spec
+    x, y = ctx.saved_tensors
+    dy = dy.contiguous()
+    if spec.act != L.ACT_NONE:      # epilogue activation backward on the saved output
+        g = torch.empty_like(dy)
+        L.check(L.lib().uig_act_bwd(_p(dy), _p(y), _p(g), dy.numel(), spec.act, spec.slope, _dt(dy), _stream()), "uig_act_bwd")
+        dy = g
+    dy = _dy_padded(spec, dy)
+    npar = len(layers)
+    need_x = ctx.needs_input_grad[0]
+    need_w = [ctx.needs_input_grad[1 + 2 * i] for i in range(npar)]
+    need_b = [ctx.needs_input_grad[2 + 2 * i] for i in range(npar)]
+    any_p = any(need_w) or any(need_b)
+    pair = None if npar == 1 else (layers[1].wp_dgrad, None, group)
+    par = need_x and any_p and PARALLEL_BACKWARD
+    main = torch.cuda.current_stream(dy.device)
+    dx = None
+    if need_x and not par:
+        dx = conv_dgrad(spec, dy, layers[0].wp_dgrad, ctx.in_hw, pair)
+    grads = []
+    if par:
+        side = _side_stream(dy.device)
+        side.wait_stream(main)
+    with (torch.cuda.stream(side) if par else contextlib.nullcontext()):
+        for i, layer in enumerate(layers):
+            if npar == 1:
+                xs, dys = x, dy
+            else:
+                xs, dys = (x[:group], dy[:group]) if i == 0 else (x[group:], dy[group:])
+            grads.extend(_param_grads(layer, spec, xs, dys, need_w[i], need_b[i]))
+    if par:
+        dx = conv_dgrad(spec, dy, layers[0].wp_dgrad, ctx.in_hw, pair)
+        main.wait_stream(side)
+    return (dx, *grads)
+
+
 class ConvFn(Function):
     """y = act(conv(x, W) + b) on physical NHWC tensors; backward = dgrad / wgrad / bias-grad HIP kernels."""
 
@@ -243,54 +314,25 @@ class ConvFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        layer = ctx.layer
-        spec = layer.spec
-        x, y = ctx.saved_tensors
-        dy = dy.contiguous()
-        if spec.act != L.ACT_NONE:      # epilogue activation backward on the saved output
-            g = torch.empty_like(dy)
-            L.check(L.lib().uig_act_bwd(_p(dy), _p(y), _p(g), dy.numel(), spec.act, spec.slope, _dt(dy), _stream()), "uig_act_bwd")
-            dy = g
-        dy = _dy_padded(spec, dy)
-        dx = dW = db = None
-        # The input gradient and the parameter gradients are independent given dy: fork the parameter-gradient kernels
-        # onto a side stream and join before returning.  The input-gradient grid rarely fills a whole number of rounds
-        # on 256 CUs (e.g. 288 tiles), and the weight-gradient blocks soak up the idle CUs of its tail.  Safe for the
-        # caching allocator (and capturable into a HIP graph): the join orders every later use of dy / x after the fork.
-        need_par = ctx.needs_input_grad[0] and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and PARALLEL_BACKWARD
-        main = torch.cuda.current_stream(dy.device)
-        side = _side_stream(dy.device) if need_par else None
-        if ctx.needs_input_grad[0] and not need_par:
-            dx = conv_dgrad(spec, dy, layer.wp_dgrad, ctx.in_hw)
-        if need_par:
-            side.wait_stream(main)
-        pctx = torch.cuda.stream(side) if need_par else contextlib.nullcontext()
-        with pctx:
-            dW, db = ConvFn._param_grads(ctx, layer, spec, x, dy)
-        if need_par:
-            dx = conv_dgrad(spec, dy, layer.wp_dgrad, ctx.in_hw)
-            main.wait_stream(side)
-        return dx, dW, db, None
+        return (*_conv_backward(ctx, dy, (ctx.layer,), 0), None)
+
+
+class PairConvFn(Function):
+    """The same layer of TWO networks of identical architecture in one launch: the first `group` images of x go through
+    layer1, the rest through layer2 (CycleGAN: G_A / G_B and D_A / D_B always see same-shaped batches).  Halves the launch
+    count and doubles the tiles per launch, which is what fills 256 CUs at a per-GPU batch of 4."""
 
     @staticmethod
-    def _param_grads(ctx, layer, spec, x, dy):
-        dW = db = None
-        # Parameter gradients: when the parameter already owns a .grad buffer (the trainer's flat gradient buffer, or any
-        # earlier backward) the reduce kernels ADD into it in place and autograd gets None (= nothing more to accumulate):
-        # gradient-accumulation fusion, no temporary dW and no extra add kernel.  Otherwise return them the usual way.
-        if ctx.needs_input_grad[1]:
-            w = layer.weight
-            if layer.fuse_grad_accum and w.grad is not None and w.grad.is_contiguous():
-                conv_wgrad(spec, x, dy, out=w.grad, accumulate=True)
-            else:
-                dW = conv_wgrad(spec, x, dy)
-        if ctx.needs_input_grad[2]:
-            b = layer.bias
-            if layer.fuse_grad_accum and b.grad is not None and b.grad.is_contiguous():
-                bias_grad(dy, spec.cout, out=b.grad, accumulate=True)
-            else:
-                db = bias_grad(dy, spec.cout)
-        return dW, db
+    def forward(ctx, x, w1, b1, w2, b2, layer1, layer2, group):
+        spec = layer1.spec
+        y = conv_forward(spec, x, layer1.wp_fwd, b1, pair=(layer2.wp_fwd, b2, group))
+        ctx.layers, ctx.group, ctx.in_hw = (layer1, layer2), group, (x.shape[1], x.shape[2])
+        ctx.save_for_backward(x, y if spec.act != L.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return (*_conv_backward(ctx, dy, ctx.layers, ctx.group), None, None, None)
 
 
 # ----------------------------------------------------------------------------------------- instance norm (+act, +residual)
