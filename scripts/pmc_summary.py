@@ -10,7 +10,7 @@ for name in ("fetch", "write", "sq"):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
-        if "igemm_kernel" in r["Kernel_Name"]:
+        if "conv_strip_kernel" in r["Kernel_Name"] or "igemm_kernel" in r["Kernel_Name"]:
             res["kernel"] = r["Kernel_Name"].split("(")[0]
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
@@ -18,13 +18,14 @@ for name in ("fetch", "write", "sq"):
 st = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")
 if st:
     for r in csv.DictReader(open(st[0])):
-        if "igemm_kernel" in r["Name"]:
+        if "conv_strip_kernel" in r["Name"] or "igemm_kernel" in r["Name"]:
             res["avg_duration_us"] = float(r["AverageNs"]) / 1e3; res["calls"] = int(r["Calls"])
 if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
     res["hbm_read_bytes_corrected"] = res["FETCH_SIZE"] * 1024 * 2
     res["hbm_write_bytes"] = res["WRITE_SIZE"] * 1024
     res["hbm_bytes_per_launch"] = res["hbm_read_bytes_corrected"] + res["hbm_write_bytes"]
-    res["algorithmic_bytes_per_launch"] = (8 * 64 * 64 * 256 * 2) * 2 + 256 * 2304 * 2
-res["workload"] = "ResBlock conv3x3 reflect 256->256 on 64x64, batch 8, bf16 (M=32768 N=256 K=2304)"
+    res["algorithmic_bytes_per_launch"] = (16 * 64 * 64 * 256 * 2) * 2 + 2 * 256 * 2304 * 2
+res["images"], res["hw"] = 16, 64
+res["workload"] = "ResBlock conv3x3 reflect 256->256 on 64x64, paired G_A|G_B launch over 16 images, bf16 (M=65536 N=256 K=2304)"
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

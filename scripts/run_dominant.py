@@ -1,5 +1,5 @@
-"""Launch the dominant kernel (ResBlock 3x3 reflect conv 256->256 on 64x64, batch 8 = the batch-2B launch of the batch-4
-step) N times on random data; used under rocprofv3 (--kernel-trace --stats, and separate --pmc passes)."""
+"""Launch the dominant kernel (ResBlock 3x3 reflect conv 256->256 on 64x64, 16 images = the paired G_A|G_B launch of the
+batch-4 step) N times on random data; used under rocprofv3 (--kernel-trace --stats, and separate --pmc passes)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,9 +9,10 @@ from unpaired_image_generation_amd import ops, networks
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 dt = torch.bfloat16
 layer = networks.ConvLayer("conv", 256, 256, 3, 1, 1, "reflect", dtype=dt, device="cuda")
-layer.repack()
-x = (torch.rand(8, 64, 64, 256, device="cuda") * 2 - 1).to(dt)
+layer2 = networks.ConvLayer("conv", 256, 256, 3, 1, 1, "reflect", dtype=dt, device="cuda")
+layer.repack(); layer2.repack()
+x = (torch.rand(16, 64, 64, 256, device="cuda") * 2 - 1).to(dt)     # the paired 4B-image launch of the batch-4 step
 for _ in range(n):
-    y = ops.conv_forward(layer.spec, x, layer.wp_fwd, layer.bias)
+    y = ops.conv_forward(layer.spec, x, layer.wp_fwd, layer.bias, pair=(layer2.wp_fwd, layer2.bias, 8))
 torch.cuda.synchronize()
 print("done", float(y.float().abs().mean()))
