@@ -24,7 +24,9 @@ template <typename T> struct WgTraits;
 template <> struct WgTraits<bf16_t> { static constexpr int PAD = 32; };
 template <> struct WgTraits<float> { static constexpr int PAD = 64; };
 
-template <typename T, int BN>
+// FASTROW: Mw % BKP == 0, so the BKP pixels of a K-step lie in ONE image row: the (image, row) part of the gather address
+// is computed once per K-step from block-uniform running coordinates and only the column part per staged row.
+template <typename T, int BN, bool FASTROW>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const T* __restrict__ P, const T* __restrict__ Q,
                                                         float* __restrict__ part, const WgradDesc d) {
     constexpr int E = ElemTraits<T>::E;
@@ -71,41 +73,63 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const T* __restrict__ P, 
     // buffer descriptors: invalid rows / zero padding use an out-of-range offset (hardware returns zeros)
     const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Q), 0, d.q_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(P), 0, d.p_bytes, 0x00020000);
-    // running pixel coordinates (b, i, j) of each Q row of the K-step being loaded: one division at the start, then
-    // incremental updates (the per-K-step divisions made this loop VALU-bound: ~250 VALU per 16 MFMAs)
+    // running pixel coordinates of the K-step being loaded: one division at the start, then incremental updates (per-K-step
+    // divisions made this loop VALU-bound: ~250 VALU per 16 MFMAs).  FASTROW keeps ONE block-uniform (b0, i0, j0).
     int qj[QI], qi[QI], qb[QI];
-#pragma unroll
-    for (int i = 0; i < QI; ++i) {
-        const int m = m_begin + q_row[i];
-        qj[i] = m % d.Mw; const int t = m / d.Mw; qi[i] = t % d.Mh; qb[i] = t / d.Mh;
-    }
-    const bool refl = d.pad_mode == UIG_PAD_REFLECT;
-    auto load_tile = [&](int ks) {
-        const int mk = m_begin + ks * BKP;
+    int j0 = 0, i0 = 0, b0 = 0;
+    if constexpr (FASTROW) {
+        j0 = m_begin % d.Mw; const int t = m_begin / d.Mw; i0 = t % d.Mh; b0 = t / d.Mh;
+    } else {
 #pragma unroll
         for (int i = 0; i < QI; ++i) {
-            const int m = mk + q_row[i];
-            const int hi = qi[i] * d.stride + q_dh[i], wi = qj[i] * d.stride + q_dw[i];
-            const bool inb = ((unsigned)hi < (unsigned)d.Hq) & ((unsigned)wi < (unsigned)d.Wq);
-            const bool ok = q_ok[i] & (m < m_end) & (refl | inb);
-            const int hr = refl ? reflect_idx(hi, d.Hq) : hi, wr = refl ? reflect_idx(wi, d.Wq) : wi;
-            const unsigned off = ok ? (unsigned)((((qb[i] * d.Hq + hr) * d.Wq + wr) * d.Cq + q_c[i]) * (int)sizeof(T)) : 0xFFFFFFFFu;
-            rq[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsq, (int)off, 0, 0));
-            // advance this row by BKP pixels for the next call
-            if (d.Mw >= BKP) {
-                qj[i] += BKP;
-                if (qj[i] >= d.Mw) { qj[i] -= d.Mw; if (++qi[i] == d.Mh) { qi[i] = 0; ++qb[i]; } }
-            } else {
+            const int m = m_begin + q_row[i];
+            qj[i] = m % d.Mw; const int t = m / d.Mw; qi[i] = t % d.Mh; qb[i] = t / d.Mh;
+        }
+    }
+    const bool refl = d.pad_mode == UIG_PAD_REFLECT;
+    unsigned poff[PI];
+#pragma unroll
+    for (int i = 0; i < PI; ++i) poff[i] = (unsigned)(((m_begin + p_row[i]) * d.Np + p_n[i]) * (int)sizeof(T));
+    auto load_tile = [&](int ks) {
+        const int mk = m_begin + ks * BKP;
+        if constexpr (FASTROW) {
+            // all staged rows share the image row: (image, row) term once, column term per row.  The tap (dh, dw) and the
+            // channel chunk are the same for every row slot of a thread (256 % QCH == 0).
+            const int hi = i0 * d.stride + q_dh[0];
+            const bool inb_h = (unsigned)hi < (unsigned)d.Hq;
+            const int hr = refl ? reflect_idx(hi, d.Hq) : hi;
+            const int rowoff = (b0 * d.Hq + hr) * d.Wq;
+#pragma unroll
+            for (int i = 0; i < QI; ++i) {
+                const int wi = (j0 + q_row[i]) * d.stride + q_dw[0];
+                const bool inb = inb_h & ((unsigned)wi < (unsigned)d.Wq);
+                const bool ok = q_ok[i] & (mk + q_row[i] < m_end) & (refl | inb);
+                const int wr = refl ? reflect_idx(wi, d.Wq) : wi;
+                const unsigned off = ok ? (unsigned)(((rowoff + wr) * d.Cq + q_c[0]) * (int)sizeof(T)) : 0xFFFFFFFFu;
+                rq[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsq, (int)off, 0, 0));
+            }
+            j0 += BKP;
+            if (j0 >= d.Mw) { j0 = 0; if (++i0 == d.Mh) { i0 = 0; ++b0; } }
+        } else {
+#pragma unroll
+            for (int i = 0; i < QI; ++i) {
+                const int m = mk + q_row[i];
+                const int hi = qi[i] * d.stride + q_dh[i], wi = qj[i] * d.stride + q_dw[i];
+                const bool inb = ((unsigned)hi < (unsigned)d.Hq) & ((unsigned)wi < (unsigned)d.Wq);
+                const bool ok = q_ok[i] & (m < m_end) & (refl | inb);
+                const int hr = refl ? reflect_idx(hi, d.Hq) : hi, wr = refl ? reflect_idx(wi, d.Wq) : wi;
+                const unsigned off = ok ? (unsigned)((((qb[i] * d.Hq + hr) * d.Wq + wr) * d.Cq + q_c[i]) * (int)sizeof(T)) : 0xFFFFFFFFu;
+                rq[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsq, (int)off, 0, 0));
+                // advance this row by BKP pixels for the next call
                 const int mn = m + BKP;
                 qj[i] = mn % d.Mw; const int t = mn / d.Mw; qi[i] = t % d.Mh; qb[i] = t / d.Mh;
             }
         }
 #pragma unroll
         for (int i = 0; i < PI; ++i) {
-            const int m = mk + p_row[i];
-            const bool ok = p_ok[i] & (m < m_end);
-            const unsigned off = ok ? (unsigned)((m * d.Np + p_n[i]) * (int)sizeof(T)) : 0xFFFFFFFFu;
-            rp[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsp, (int)off, 0, 0));
+            const bool ok = p_ok[i] & (mk + p_row[i] < m_end);
+            rp[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsp, ok ? (int)poff[i] : -1, 0, 0));
+            poff[i] += (unsigned)(BKP * d.Np * (int)sizeof(T));
         }
     };
     auto store_tile = [&](int stage) {
@@ -226,11 +250,11 @@ extern "C" size_t uig_wgrad_workspace_bytes(int Np, int Cq, int kH, int kW, int 
     return (size_t)splits * Np * kH * kW * Cq * sizeof(float);
 }
 
-template <typename T, int BN>
+template <typename T, int BN, bool FASTROW>
 static int launch_wgrad(const void* P, const void* Q, float* ws, const WgradDesc& d, int splits, hipStream_t s) {
     constexpr int PROW = BN * (int)sizeof(T) + WgTraits<T>::PAD, QROW = 128 * (int)sizeof(T) + WgTraits<T>::PAD;
     const size_t smem = 2 * (size_t)(sizeof(T) == 2 ? 64 : 32) * (size_t)(PROW + QROW);
-    auto kern = wgrad_kernel<T, BN>;
+    auto kern = wgrad_kernel<T, BN, FASTROW>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -266,9 +290,14 @@ extern "C" int uig_wgrad_partial(const void* P, const void* Q, float* workspace,
     const long esz = dtype == UIG_BF16 ? 2 : 4;
     d.p_bytes = (unsigned)((long)B * Mh * Mw * Np * esz); d.q_bytes = (unsigned)((long)B * Hq * Wq * Cq * esz);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == UIG_BF16)
-        return Np <= 16 ? launch_wgrad<bf16_t, 16>(P, Q, workspace, d, splits, s) : launch_wgrad<bf16_t, 128>(P, Q, workspace, d, splits, s);
-    return Np <= 16 ? launch_wgrad<float, 16>(P, Q, workspace, d, splits, s) : launch_wgrad<float, 128>(P, Q, workspace, d, splits, s);
+    const int bkp = dtype == UIG_BF16 ? 64 : 32;
+    const bool fast = (Mw % bkp) == 0;          // a K-step never leaves its image row (Mper is a multiple of bkp)
+    if (dtype == UIG_BF16) {
+        if (Np <= 16) return fast ? launch_wgrad<bf16_t, 16, true>(P, Q, workspace, d, splits, s) : launch_wgrad<bf16_t, 16, false>(P, Q, workspace, d, splits, s);
+        return fast ? launch_wgrad<bf16_t, 128, true>(P, Q, workspace, d, splits, s) : launch_wgrad<bf16_t, 128, false>(P, Q, workspace, d, splits, s);
+    }
+    if (Np <= 16) return fast ? launch_wgrad<float, 16, true>(P, Q, workspace, d, splits, s) : launch_wgrad<float, 16, false>(P, Q, workspace, d, splits, s);
+    return fast ? launch_wgrad<float, 128, true>(P, Q, workspace, d, splits, s) : launch_wgrad<float, 128, false>(P, Q, workspace, d, splits, s);
 }
 
 extern "C" int uig_wgrad_reduce(const float* workspace, float* dW, int Np, int Cq, int taps, int splits,
