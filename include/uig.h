@@ -95,6 +95,15 @@ int uig_instnorm_act_fwd(const void* x, const void* residual, void* y, float* st
 int uig_instnorm_act_bwd(const void* dy, const void* x, const float* stats, void* dx, float* workspace,
                          int B, int64_t HW, int C, int act, float slope, int dtype, void* stream);
 
+/* Same, and additionally emits per-block column sums of the dx it writes into colsum_partial
+ * (fp32[uig_instnorm_bwd_colsum_slabs(B,HW,C,dtype) * C * 2]): the bias gradient of the convolution in front of this
+ * InstanceNorm is then uig_bias_grad_from_partials(colsum_partial, db, slabs, ...) with no second pass over dx. */
+int uig_instnorm_bwd_colsum_slabs(int B, int64_t HW, int C, int dtype);
+int uig_instnorm_act_bwd_colsum(const void* dy, const void* x, const float* stats, void* dx, float* workspace,
+                                float* colsum_partial, int B, int64_t HW, int C, int act, float slope, int dtype, void* stream);
+int uig_bias_grad_from_partials(const float* colsum_partial, float* db, int nslab_total, int C, int Nreal,
+                                int accumulate, void* stream);
+
 /* aten::reflection_pad2d_backward: fold (B,H+2p,W+2p,C) -> (B,H,W,C) */
 int uig_reflect_fold(const void* dyp, void* dx, int B, int H, int W, int C, int pad, int dtype, void* stream);
 /* aten::tanh_backward / leaky_relu_backward / threshold_backward on the activation OUTPUT y: dx = dy * act'(y) */

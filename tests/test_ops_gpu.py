@@ -209,3 +209,26 @@ def test_layout_roundtrip_and_reflect_fold():
         dx = torch.empty(2, H, W, 16, device="cuda")
         u.lib.check(u.lib.lib().uig_reflect_fold(dypp.data_ptr(), dx.data_ptr(), 2, H, W, 16, P, 0, torch.cuda.current_stream().cuda_stream), "fold")
         assert (ops.from_nhwc(dx, 16).cpu() - ref.grad).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_instnorm_bwd_colsum_partials(dtype):
+    """The InstanceNorm backward emits per-block column sums of the dx it writes (the bias gradient of the conv in front
+    of it).  Finalised, they must equal the column sums of dx itself, per network half of a paired batch."""
+    u, ops, networks = _mods()
+    torch.manual_seed(17)
+    B, H, W, C = 6, 24, 20, 128
+    x = (torch.randn(B, H, W, C, device="cuda") * 2 + 0.3).to(dtype).requires_grad_(True)
+    y = networks.InstNormAct(u.lib.ACT_RELU)(x)
+    y.backward(torch.randn_like(y))
+    dx = x.grad
+    cs = dx._uig_colsum
+    assert cs[2] == C and cs[1] >= 1
+    for img0, nimg in ((0, B), (0, 2), (2, 4)):
+        got = ops._bias_grad_from_partials(cs, img0, nimg, C, None, False).cpu()
+        ref = dx[img0:img0 + nimg].float().sum(dim=(0, 1, 2)).cpu()
+        scale = float(dx[img0:img0 + nimg].float().abs().sum(dim=(0, 1, 2)).max())
+        assert (got - ref).abs().max() <= 2e-6 * scale + 1e-6, (img0, nimg, float((got - ref).abs().max()), scale)
+    acc = torch.ones(C, device="cuda")
+    ops._bias_grad_from_partials(cs, 0, B, C, acc, True)
+    assert (acc.cpu() - 1 - dx.float().sum(dim=(0, 1, 2)).cpu()).abs().max() <= 2e-6 * scale + 1e-6

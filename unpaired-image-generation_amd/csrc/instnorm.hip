@@ -60,27 +60,25 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ x, 
 }
 
 // fin MODE 0: stats = (mean, rstd)   MODE 1: out = (mean_g, mean_gxhat)   MODE 2: db[c] (+)= sum (B folded into slabs)
-// 256 threads = 32 (b,c) items x 8 slab lanes: coalesced 256-byte partial reads, fp64 combine through LDS.
+// 256 threads = 16 (b,c) items x 16 slab lanes; fp64 combine across the slab lanes by wave shuffles (lanes of one item are
+// 16 consecutive lanes of a wave).
 __global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, int BC,
                                                            int C, int nslab, double inv_n, float eps, int mode, int nreal,
                                                            int accumulate) {
-    __shared__ double sa[8][32], sq[8][32];
-    const int ci = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + ci;
+    const int sl = threadIdx.x & 15, it = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + it;
     double a = 0.0, q = 0.0;
     int b = 0, c = 0;
     if (i < BC) {
         b = i / C; c = i % C;
-        for (int s = sl; s < nslab; s += 8) {
+        for (int s = sl; s < nslab; s += 16) {
             const float* p = partial + (((long)b * nslab + s) * C + c) * 2;
             a += (double)p[0]; q += (double)p[1];
         }
     }
-    sa[sl][ci] = a; sq[sl][ci] = q;
-    __syncthreads();
-    if (sl != 0 || i >= BC) return;
 #pragma unroll
-    for (int s = 1; s < 8; ++s) { a += sa[s][ci]; q += sq[s][ci]; }
+    for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 16); q += __shfl_xor(q, o, 16); }
+    if (sl != 0 || i >= BC) return;
     if (mode == 0) {
         const double mean = a * inv_n;
         double var = q * inv_n - mean * mean;
@@ -124,23 +122,27 @@ __global__ __launch_bounds__(256) void in_apply_fwd_kernel(const T* __restrict__
     }
 }
 
-template <typename T>
+// COLSUM: additionally emit per-block partial sums of the written dx (as stored, i.e. after rounding to T) per channel:
+// the bias gradient of the convolution in front of this InstanceNorm is the column sum of exactly this tensor, so the
+// separate full read pass of uig_bias_grad disappears (it sat on the backward critical path).
+template <typename T, bool COLSUM>
 __global__ __launch_bounds__(256) void in_apply_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             T* __restrict__ dx, const float* __restrict__ stats,
-                                                            const float* __restrict__ gm, long HW, int C, int CC,
-                                                            int nslab, int act, float slope) {
+                                                            const float* __restrict__ gm, float* __restrict__ colsum_partial,
+                                                            long HW, int C, int CC, int nslab, int act, float slope) {
     constexpr int E = ElemTraits<T>::E;
+    __shared__ float red[COLSUM ? 256 * E : 1];
     const int tid = threadIdx.x;
     const int PL = 256 / CC, pl = tid / CC, cc = tid % CC;
     const int b = blockIdx.y;
     const long sp = (HW + nslab - 1) / nslab;
     const long p0 = blockIdx.x * sp, p1 = min(HW, p0 + sp);
     const long base = (long)b * HW * C + cc * E;
-    float mu[E], rs[E], mg[E], mgx[E];
+    float mu[E], rs[E], mg[E], mgx[E], cs[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const long i = ((long)b * C + cc * E + e) * 2;
-        mu[e] = stats[i]; rs[e] = stats[i + 1]; mg[e] = gm[i]; mgx[e] = gm[i + 1];
+        mu[e] = stats[i]; rs[e] = stats[i + 1]; mg[e] = gm[i]; mgx[e] = gm[i + 1]; cs[e] = 0.f;
     }
     for (long p = p0 + pl; p < p1; p += PL) {
         float xv[E], gv[E];
@@ -154,7 +156,25 @@ __global__ __launch_bounds__(256) void in_apply_bwd_kernel(const T* __restrict__
             else if (act == UIG_ACT_LRELU) g = xh > 0.f ? g : g * slope;
             gv[e] = rs[e] * (g - mg[e] - xh * mgx[e]);
         }
-        *reinterpret_cast<u32x4_t*>(dx + base + p * C) = f32_to_chunk<T>(gv);
+        const u32x4_t packed = f32_to_chunk<T>(gv);
+        *reinterpret_cast<u32x4_t*>(dx + base + p * C) = packed;
+        if constexpr (COLSUM) {
+            float rv[E];
+            chunk_to_f32<T>(packed, rv);
+#pragma unroll
+            for (int e = 0; e < E; ++e) cs[e] += rv[e];
+        }
+    }
+    if constexpr (COLSUM) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) red[tid * E + e] = cs[e];
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            float a = 0.f;
+            for (int l = 0; l < PL; ++l) a += red[l * C + c];
+            float* out = colsum_partial + (((long)b * nslab + blockIdx.x) * C + c) * 2;
+            out[0] = a; out[1] = 0.f;
+        }
     }
 }
 
@@ -190,7 +210,7 @@ extern "C" int uig_instnorm_act_fwd(const void* x, const void* residual, void* y
     else
         hipLaunchKernelGGL((in_stats_kernel<float, 0>), dim3(ns, B), dim3(256), 0, s, (const float*)x, (const float*)nullptr, (const float*)nullptr, workspace, (long)HW, C, CC, ns, 0, 0.f);
     UIG_LAUNCH_CHECK("uig_instnorm_act_fwd(stats)");
-    hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 31) / 32), dim3(256), 0, s, workspace, stats, B * C, C, ns, 1.0 / (double)HW, eps, 0, 0, 0);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 15) / 16), dim3(256), 0, s, workspace, stats, B * C, C, ns, 1.0 / (double)HW, eps, 0, 0, 0);
     UIG_LAUNCH_CHECK("uig_instnorm_act_fwd(finalize)");
     if (dtype == UIG_BF16)
         hipLaunchKernelGGL((in_apply_fwd_kernel<bf16_t>), dim3(na, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, stats, (long)HW, C, CC, na, act, slope);
@@ -200,26 +220,59 @@ extern "C" int uig_instnorm_act_fwd(const void* x, const void* residual, void* y
     return 0;
 }
 
-extern "C" int uig_instnorm_act_bwd(const void* dy, const void* x, const float* stats, void* dx, float* workspace,
-                                    int B, int64_t HW, int C, int act, float slope, int dtype, void* stream) {
+static int colsum_slabs(long HW, int CC) { return (int)std::max<long>(1, std::min<long>(32, HW * CC / (256 * 4))); }
+extern "C" int uig_instnorm_bwd_colsum_slabs(int B, int64_t HW, int C, int dtype) {
+    const int E = dtype == UIG_BF16 ? 8 : 4;
+    return B * colsum_slabs(HW, C / E);
+}
+
+static int instnorm_bwd_impl(const void* dy, const void* x, const float* stats, void* dx, float* workspace, float* colsum_partial,
+                             int B, int64_t HW, int C, int act, float slope, int dtype, void* stream) {
     UIG_CHECK_ARG(dy && x && stats && dx && workspace, "uig_instnorm_act_bwd: null pointer");
     UIG_CHECK_ARG(act == UIG_ACT_NONE || act == UIG_ACT_RELU || act == UIG_ACT_LRELU, "uig_instnorm_act_bwd: bad act %d", act);
     int CC; if (int r = check_in_args("uig_instnorm_act_bwd", B, HW, C, dtype, &CC)) return r;
     hipStream_t s = (hipStream_t)stream;
-    const int ns = stats_slabs(HW, CC), na = apply_slabs(HW, CC);
+    const int ns = stats_slabs(HW, CC), na = colsum_partial ? colsum_slabs(HW, CC) : apply_slabs(HW, CC);
     float* gm = workspace + (size_t)B * 128 * C * 2;
     if (dtype == UIG_BF16)
         hipLaunchKernelGGL((in_stats_kernel<bf16_t, 1>), dim3(ns, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, stats, workspace, (long)HW, C, CC, ns, act, slope);
     else
         hipLaunchKernelGGL((in_stats_kernel<float, 1>), dim3(ns, B), dim3(256), 0, s, (const float*)x, (const float*)dy, stats, workspace, (long)HW, C, CC, ns, act, slope);
     UIG_LAUNCH_CHECK("uig_instnorm_act_bwd(stats)");
-    hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 31) / 32), dim3(256), 0, s, workspace, gm, B * C, C, ns, 1.0 / (double)HW, 0.f, 1, 0, 0);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 15) / 16), dim3(256), 0, s, workspace, gm, B * C, C, ns, 1.0 / (double)HW, 0.f, 1, 0, 0);
     UIG_LAUNCH_CHECK("uig_instnorm_act_bwd(finalize)");
-    if (dtype == UIG_BF16)
-        hipLaunchKernelGGL((in_apply_bwd_kernel<bf16_t>), dim3(na, B), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, stats, gm, (long)HW, C, CC, na, act, slope);
-    else
-        hipLaunchKernelGGL((in_apply_bwd_kernel<float>), dim3(na, B), dim3(256), 0, s, (const float*)dy, (const float*)x, (float*)dx, stats, gm, (long)HW, C, CC, na, act, slope);
+    if (colsum_partial) {
+        if (dtype == UIG_BF16)
+            hipLaunchKernelGGL((in_apply_bwd_kernel<bf16_t, true>), dim3(na, B), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, stats, gm, colsum_partial, (long)HW, C, CC, na, act, slope);
+        else
+            hipLaunchKernelGGL((in_apply_bwd_kernel<float, true>), dim3(na, B), dim3(256), 0, s, (const float*)dy, (const float*)x, (float*)dx, stats, gm, colsum_partial, (long)HW, C, CC, na, act, slope);
+    } else {
+        if (dtype == UIG_BF16)
+            hipLaunchKernelGGL((in_apply_bwd_kernel<bf16_t, false>), dim3(na, B), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, stats, gm, (float*)nullptr, (long)HW, C, CC, na, act, slope);
+        else
+            hipLaunchKernelGGL((in_apply_bwd_kernel<float, false>), dim3(na, B), dim3(256), 0, s, (const float*)dy, (const float*)x, (float*)dx, stats, gm, (float*)nullptr, (long)HW, C, CC, na, act, slope);
+    }
     UIG_LAUNCH_CHECK("uig_instnorm_act_bwd(apply)");
+    return 0;
+}
+
+extern "C" int uig_instnorm_act_bwd(const void* dy, const void* x, const float* stats, void* dx, float* workspace,
+                                    int B, int64_t HW, int C, int act, float slope, int dtype, void* stream) {
+    return instnorm_bwd_impl(dy, x, stats, dx, workspace, nullptr, B, HW, C, act, slope, dtype, stream);
+}
+
+extern "C" int uig_instnorm_act_bwd_colsum(const void* dy, const void* x, const float* stats, void* dx, float* workspace,
+                                           float* colsum_partial, int B, int64_t HW, int C, int act, float slope, int dtype,
+                                           void* stream) {
+    UIG_CHECK_ARG(colsum_partial, "uig_instnorm_act_bwd_colsum: null colsum_partial");
+    return instnorm_bwd_impl(dy, x, stats, dx, workspace, colsum_partial, B, HW, C, act, slope, dtype, stream);
+}
+
+extern "C" int uig_bias_grad_from_partials(const float* colsum_partial, float* db, int nslab_total, int C, int Nreal,
+                                           int accumulate, void* stream) {
+    UIG_CHECK_ARG(colsum_partial && db && nslab_total > 0 && Nreal > 0 && Nreal <= C, "uig_bias_grad_from_partials: bad args");
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, colsum_partial, db, C, C, nslab_total, 1.0, 0.f, 2, Nreal, accumulate);
+    UIG_LAUNCH_CHECK("uig_bias_grad_from_partials");
     return 0;
 }
 
@@ -235,7 +288,7 @@ extern "C" int uig_bias_grad(const void* dy, float* db, float* workspace, int64_
     else
         hipLaunchKernelGGL((in_stats_kernel<float, 0>), dim3(ns, 1), dim3(256), 0, s, (const float*)dy, (const float*)nullptr, (const float*)nullptr, workspace, (long)pixels, C, CC, ns, 0, 0.f);
     UIG_LAUNCH_CHECK("uig_bias_grad(partial)");
-    hipLaunchKernelGGL(in_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, workspace, db, C, C, ns, 1.0, 0.f, 2, Nreal, accumulate);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, workspace, db, C, C, ns, 1.0, 0.f, 2, Nreal, accumulate);
     UIG_LAUNCH_CHECK("uig_bias_grad(finalize)");
     return 0;
 }

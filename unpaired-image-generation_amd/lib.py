@@ -36,6 +36,9 @@ SIGNATURES = {
     "uig_instnorm_workspace_floats": (_sz, [_i, _i64, _i]),
     "uig_instnorm_act_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _i, _f, _i, _vp]),
     "uig_instnorm_act_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _vp]),
+    "uig_instnorm_bwd_colsum_slabs": (_i, [_i, _i64, _i, _i]),
+    "uig_instnorm_act_bwd_colsum": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _vp]),
+    "uig_bias_grad_from_partials": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "uig_reflect_fold": (_i, [_vp, _vp] + [_i] * 6 + [_vp]),
     "uig_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _f, _i, _vp]),
     "uig_l1_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f, _i, _vp]),

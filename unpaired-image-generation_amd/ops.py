@@ -239,7 +239,17 @@ def bias_grad(dy: torch.Tensor, nreal: int, out: torch.Tensor | None = None, acc
     return out
 
 
-def _param_grads(layer, spec, x, dy, need_w, need_b):
+def _bias_grad_from_partials(cs, img0, nimg, nreal, out, accumulate):
+    cpart, slabs_per_img, C = cs
+    sub = cpart[img0 * slabs_per_img * C * 2:]
+    if out is None:
+        out, accumulate = torch.empty((nreal,), device=cpart.device, dtype=torch.float32), False
+    L.check(L.lib().uig_bias_grad_from_partials(_p(sub), _p(out), nimg * slabs_per_img, C, nreal, 1 if accumulate else 0, _stream()),
+            "uig_bias_grad_from_partials")
+    return out
+
+
+def _param_grads(layer, spec, x, dy, need_w, need_b, colsum=None, img0=0):
     """dW / db of one layer.  When the parameter already owns a .grad buffer (the trainer's flat gradient buffer, or any
     earlier backward) the reduce kernels ADD into it in place and autograd gets None (= nothing more to accumulate):
     gradient-accumulation fusion, no temporary dW and no extra add kernel.  Otherwise they are returned the usual way."""
@@ -252,7 +262,11 @@ def _param_grads(layer, spec, x, dy, need_w, need_b):
             dW = conv_wgrad(spec, x, dy)
     if need_b:
         b = layer.bias
-        if layer.fuse_grad_accum and b.grad is not None and b.grad.is_contiguous():
+        fused = layer.fuse_grad_accum and b.grad is not None and b.grad.is_contiguous()
+        if colsum is not None and colsum[2] == dy.shape[3]:      # column sums already produced by the InstanceNorm backward
+            r = _bias_grad_from_partials(colsum, img0, dy.shape[0], spec.cout, b.grad if fused else None, fused)
+            db = None if fused else r
+        elif fused:
             bias_grad(dy, spec.cout, out=b.grad, accumulate=True)
         else:
             db = bias_grad(dy, spec.cout)
@@ -267,8 +281,10 @@ def _conv_backward(ctx, dy, layers, group):
     dy / x after the fork."""
     spec = layers[0].spec
     x, y = ctx.saved_tensors
+    colsum = getattr(dy, "_uig_colsum", None) if dy.is_contiguous() else None
     dy = dy.contiguous()
-    if spec.act != L.ACT_NONE:      # epilogue activation backward on the saved output
+    if spec.act != L.ACT_NONE:
+        colsum = None      # epilogue activation backward on the saved output
         g = torch.empty_like(dy)
         L.check(L.lib().uig_act_bwd(_p(dy), _p(y), _p(g), dy.numel(), spec.act, spec.slope, _dt(dy), _stream()), "uig_act_bwd")
         dy = g
@@ -291,10 +307,10 @@ def _conv_backward(ctx, dy, layers, group):
     with (torch.cuda.stream(side) if par else contextlib.nullcontext()):
         for i, layer in enumerate(layers):
             if npar == 1:
-                xs, dys = x, dy
+                xs, dys, i0 = x, dy, 0
             else:
-                xs, dys = (x[:group], dy[:group]) if i == 0 else (x[group:], dy[group:])
-            grads.extend(_param_grads(layer, spec, xs, dys, need_w[i], need_b[i]))
+                xs, dys, i0 = (x[:group], dy[:group], 0) if i == 0 else (x[group:], dy[group:], group)
+            grads.extend(_param_grads(layer, spec, xs, dys, need_w[i], need_b[i], colsum, i0))
     if par:
         dx = conv_dgrad(spec, dy, layers[0].wp_dgrad, ctx.in_hw, pair)
         main.wait_stream(side)
@@ -359,8 +375,14 @@ class InstNormActFn(Function):
         lib = L.lib()
         ws = torch.empty((int(lib.uig_instnorm_workspace_floats(B, H * W, C)),), device=x.device, dtype=torch.float32)
         dx = torch.empty_like(x)
-        L.check(lib.uig_instnorm_act_bwd(_p(dy), _p(x), _p(stats), _p(dx), _p(ws), B, H * W, C, ctx.act, ctx.slope,
-                                         _dt(x), _stream()), "uig_instnorm_act_bwd")
+        # dx is the gradient of the convolution output in front of this norm: its per-channel column sums are that conv's
+        # bias gradient.  The apply kernel emits them as per-block partials (no second pass over dx); the conv backward
+        # picks them up through the attribute below (same tensor object: the conv output feeds only this norm).
+        slabs = int(lib.uig_instnorm_bwd_colsum_slabs(B, H * W, C, _dt(x)))
+        cpart = torch.empty((slabs * C * 2,), device=x.device, dtype=torch.float32)
+        L.check(lib.uig_instnorm_act_bwd_colsum(_p(dy), _p(x), _p(stats), _p(dx), _p(ws), _p(cpart), B, H * W, C, ctx.act,
+                                                ctx.slope, _dt(x), _stream()), "uig_instnorm_act_bwd_colsum")
+        dx._uig_colsum = (cpart, slabs // B, C)
         return dx, (dy if ctx.has_res else None), None, None, None
 
 
