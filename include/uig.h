@@ -62,6 +62,15 @@ int uig_conv_gather_pair(const void* x, const void* wp, const float* bias, const
                          int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
                          int act, float slope, int dtype, void* stream);
 
+/* Superset entry: optional second network (wp2 != NULL) and optional fused InstanceNorm statistics: in_partial
+ * (fp32[B * (Ho*Wo/64) * Nstore * 2]) receives per-64-pixel (sum, sum of squares) of the stored output per channel, consumed by
+ * uig_instnorm_act_fwd_pre.  Needs Nrows a multiple of 64 (> 64), Nstore == Nrows and (gather grid) % 64 == 0. */
+int uig_conv_gather_ex(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2,
+                       int group_images, float* in_partial, void* y,
+                       int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
+                       int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
+                       int act, float slope, int dtype, void* stream);
+
 /* aten::convolution_backward(weight grad) — dW partials by split-K MFMA GEMM over pixels, then uig_wgrad_reduce.
  *   part[s][n][tap][c] = sum_{pixels m in split s} P[m][n] * Q[pix(m,tap)][c]
  * P: dense operand (B,Mh,Mw,Np) (dy for Conv2d, x for ConvTranspose2d); Q: gathered operand (B,Hq,Wq,Cq) read at
@@ -90,6 +99,9 @@ int uig_pack_weight(const float* w, void* wp, int D0, int D1, int kH, int kW, in
 size_t uig_instnorm_workspace_floats(int B, int64_t HW, int C);
 int uig_instnorm_act_fwd(const void* x, const void* residual, void* y, float* stats, float* workspace,
                          int B, int64_t HW, int C, float eps, int act, float slope, int dtype, void* stream);
+/* the same forward with the statistics partials already produced by uig_conv_gather_ex (nslab = HW/64 per image) */
+int uig_instnorm_act_fwd_pre(const void* x, const void* residual, void* y, float* stats, const float* partial, int nslab,
+                             int B, int64_t HW, int C, float eps, int act, float slope, int dtype, void* stream);
 /* aten::native_batch_norm_backward (on the (1,B*C,H,W) view) fused with the activation's backward:
  *   g = dy * act'(xhat);  dx = rstd * (g - mean(g) - xhat * mean(g*xhat))                                   */
 int uig_instnorm_act_bwd(const void* dy, const void* x, const float* stats, void* dx, float* workspace,

@@ -218,10 +218,9 @@ def test_instnorm_bwd_colsum_partials(dtype):
     u, ops, networks = _mods()
     torch.manual_seed(17)
     B, H, W, C = 6, 24, 20, 128
-    x = (torch.randn(B, H, W, C, device="cuda") * 2 + 0.3).to(dtype).requires_grad_(True)
-    y = networks.InstNormAct(u.lib.ACT_RELU)(x)
-    y.backward(torch.randn_like(y))
-    dx = x.grad
+    x = (torch.randn(B, H, W, C, device="cuda") * 2 + 0.3).to(dtype)
+    st = torch.stack([x.float().mean(dim=(1, 2)), 1.0 / torch.sqrt(x.float().var(dim=(1, 2), unbiased=False) + 1e-5)], dim=2).contiguous()
+    dx = ops.instnorm_backward(torch.randn_like(x), x, st, u.lib.ACT_RELU, 0.0)
     cs = dx._uig_colsum
     assert cs[2] == C and cs[1] >= 1
     for img0, nimg in ((0, B), (0, 2), (2, 4)):
@@ -232,3 +231,25 @@ def test_instnorm_bwd_colsum_partials(dtype):
     acc = torch.ones(C, device="cuda")
     ops._bias_grad_from_partials(cs, 0, B, C, acc, True)
     assert (acc.cpu() - 1 - dx.float().sum(dim=(0, 1, 2)).cpu()).abs().max() <= 2e-6 * scale + 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("kind,cin,cout,k,s,p,pm,H,W", [("conv", 256, 256, 3, 1, 1, "reflect", 16, 16), ("conv", 64, 128, 3, 2, 1, "zero", 32, 32),
+                                                         ("convT", 256, 128, 3, 2, 1, "zero", 16, 16), ("conv", 64, 128, 4, 2, 1, "zero", 32, 48)])
+def test_fused_instnorm_statistics(kind, cin, cout, k, s, p, pm, H, W, dtype):
+    """conv -> InstanceNorm with the statistics accumulated in the conv epilogue (strip, direct and transposed-phase
+    kernels) equals the unfused three-kernel InstanceNorm on the same conv output."""
+    u, ops, networks = _mods()
+    torch.manual_seed(23)
+    layer = networks.ConvLayer(kind, cin, cout, k, s, p, pm, dtype=dtype, device="cuda")
+    norm = networks.InstNormAct(u.lib.ACT_RELU)
+    x = (torch.rand(3, H, W, cin, device="cuda") * 2 - 1).to(dtype)
+    layer.emit_in_stats = True
+    c1 = layer(x)
+    assert hasattr(c1, "_uig_in_partial"), "fusion rule did not fire"
+    y1 = norm(c1)
+    layer.emit_in_stats = False
+    c2 = layer(x)
+    assert not hasattr(c2, "_uig_in_partial") and torch.equal(c1, c2)
+    y2 = norm(c2)
+    assert (y1.float() - y2.float()).abs().max() <= (2e-5 if dtype == torch.float32 else 2e-2)

@@ -33,6 +33,7 @@ struct GatherDesc {
     const void* wp2;       // paired launch: GEMM rows >= group_rows (the second network's images) use wp2 / bias2
     const float* bias2;
     int group_rows;
+    float* in_partial;     // optional: InstanceNorm partial statistics [img][Ho*Wo/64][Nstore][2] (needs Mh*Mw % 64 == 0)
 };
 
 template <typename T> struct Mma;
@@ -257,8 +258,14 @@ void igemm_kernel(const T* __restrict__ x, const T* __restrict__ wp_, const floa
                     b4[a * 4 + e] = (bias != nullptr && n < d.Nrows) ? bias[n] : 0.f;
                 }
             const int mw = m_base + wm * WM;
+            float* so = nullptr;
+            if (d.in_partial != nullptr && mw < M) {      // the wave's 64 rows lie in one image (Mh*Mw % 64 == 0, host-checked)
+                const int per = d.Mh * d.Mw, im = mw / per, loc = mw - im * per;
+                so = d.in_partial + (((long)im * (d.nphase * (per / 64)) + ph * (per / 64) + loc / 64) * d.Nstore + nw0) * 2;
+            }
             store_tile_via_lds<T, MT, NT>(acc, smem + wave * (64 * 64 * (int)sizeof(T)), lane, b4, d.act, d.slope,
-                                          [&](int r) -> T* { T* pp = out_row(mw + r); return pp ? pp + nw0 : nullptr; });
+                                          [&](int r) -> T* { T* pp = out_row(mw + r); return pp ? pp + nw0 : nullptr; },
+                                          so, min(64, M - mw));
             return;
         }
     }
@@ -346,14 +353,14 @@ static int dispatch_igemm(const void* x, const void* wp, const float* bias, void
 }
 
 int uig_try_conv_strip(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
-                       void* y, int B, int H, int W, int Cin, int Nrows,
+                       float* in_partial, void* y, int B, int H, int W, int Cin, int Nrows,
                        int k, int pad_mode, const int* taps, int ntaps, int dh_min, int dh_max, int Ho, int Wo, int ldc, int Nstore,
                        int act, float slope, int dtype, long x_bytes, long w_bytes, hipStream_t s, int* rc_out);
 
 static int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
 static int conv_gather_impl(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
-                            void* y, int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
+                            float* in_partial, void* y, int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
                             int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
                             int act, float slope, int dtype, void* stream) {
     UIG_CHECK_ARG(x && wp && y, "uig_conv_gather: null pointer");
@@ -412,11 +419,17 @@ static int conv_gather_impl(const void* x, const void* wp, const float* bias, co
         for (int p = 0; p < d.nphase; ++p)
             UIG_CHECK_ARG(d.ph_tap0[p + 1] > d.ph_tap0[p], "uig_conv_gather: transposed phase %d has no taps (k=%dx%d s=%d p=%d)", p, kH, kW, stride, pad);
     }
+    if (in_partial != nullptr) {     // fused InstanceNorm statistics need the full-row LDS epilogue on every wave
+        UIG_CHECK_ARG(Nrows > 64 && Nrows % 64 == 0 && Nstore == Nrows && (d.Mh * d.Mw) % 64 == 0 && Ho % d.so == 0 && Wo % d.so == 0 &&
+                      (ldc * (dtype == UIG_BF16 ? 2 : 4)) % 16 == 0 && g_force_tile == 0,
+                      "uig_conv_gather_ex: fused IN statistics unsupported for this shape (N=%d, %dx%d)", Nrows, d.Mh, d.Mw);
+        d.in_partial = in_partial;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (d.nphase == 1 && stride == 1 && kH == kW) {      // stride-1 k x k: LDS-resident input strip kernel (conv_strip.hip)
         int dmin = 127, dmax = -127, rc = 0;
         for (int t = 0; t < kH * kW; ++t) { const int dh = (d.tap[t] & 255) - 128; dmin = std::min(dmin, dh); dmax = std::max(dmax, dh); }
-        if (uig_try_conv_strip(x, wp, bias, wp2, bias2, group_images, y, B, H, W, Cin, Nrows, kH, pad_mode, d.tap, kH * kW, dmin, dmax,
+        if (uig_try_conv_strip(x, wp, bias, wp2, bias2, group_images, in_partial, y, B, H, W, Cin, Nrows, kH, pad_mode, d.tap, kH * kW, dmin, dmax,
                                Ho, Wo, ldc, Nstore, act, slope, dtype, (long)d.x_bytes, (long)d.w_bytes, s, &rc))
             return rc;
     }
@@ -424,11 +437,12 @@ static int conv_gather_impl(const void* x, const void* wp, const float* bias, co
         const long grows = (long)group_images * d.Mh * d.Mw;
         if (grows % 256 != 0) {      // a tile could straddle the two groups: run them as two launches (same results)
             const long esz2 = dtype == UIG_BF16 ? 2 : 4;
-            int rc = conv_gather_impl(x, wp, bias, nullptr, nullptr, 0, y, group_images, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode,
+            const long pstride = (long)(Ho * Wo / 64) * Nstore * 2;
+            int rc = conv_gather_impl(x, wp, bias, nullptr, nullptr, 0, in_partial, y, group_images, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode,
                                       gather_mode, Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
             if (rc) return rc;
             return conv_gather_impl((const char*)x + (long)group_images * H * W * Cin * esz2, wp2, bias2, nullptr, nullptr, 0,
-                                    (char*)y + (long)group_images * Ho * Wo * ldc * esz2, B - group_images, H, W, Cin, Nrows, kH, kW,
+                                    in_partial ? in_partial + group_images * pstride : nullptr, (char*)y + (long)group_images * Ho * Wo * ldc * esz2, B - group_images, H, W, Cin, Nrows, kH, kW,
                                     stride, pad, pad_mode, gather_mode, Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
         }
         d.wp2 = wp2; d.bias2 = bias2; d.group_rows = (int)grows;
@@ -440,7 +454,7 @@ extern "C" int uig_conv_gather(const void* x, const void* wp, const float* bias,
                                int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
                                int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
                                int act, float slope, int dtype, void* stream) {
-    return conv_gather_impl(x, wp, bias, nullptr, nullptr, 0, y, B, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode, gather_mode,
+    return conv_gather_impl(x, wp, bias, nullptr, nullptr, 0, nullptr, y, B, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode, gather_mode,
                             Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
 }
 
@@ -450,6 +464,15 @@ extern "C" int uig_conv_gather_pair(const void* x, const void* wp, const float* 
                                     int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
                                     int act, float slope, int dtype, void* stream) {
     UIG_CHECK_ARG(wp2 != nullptr, "uig_conv_gather_pair: null wp2");
-    return conv_gather_impl(x, wp, bias, wp2, bias2, group_images, y, B, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode, gather_mode,
+    return conv_gather_impl(x, wp, bias, wp2, bias2, group_images, nullptr, y, B, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode, gather_mode,
                             Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
+}
+
+extern "C" int uig_conv_gather_ex(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2,
+                                  int group_images, float* in_partial, void* y,
+                                  int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
+                                  int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
+                                  int act, float slope, int dtype, void* stream) {
+    return conv_gather_impl(x, wp, bias, wp2, bias2, wp2 ? group_images : 0, in_partial, y, B, H, W, Cin, Nrows, kH, kW, stride, pad,
+                            pad_mode, gather_mode, Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
 }

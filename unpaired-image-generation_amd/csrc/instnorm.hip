@@ -256,6 +256,24 @@ static int instnorm_bwd_impl(const void* dy, const void* x, const float* stats, 
     return 0;
 }
 
+// forward with the (sum, sum^2) partials already produced by the convolution's epilogue (uig_conv_gather_ex): finalize + apply
+extern "C" int uig_instnorm_act_fwd_pre(const void* x, const void* residual, void* y, float* stats, const float* partial, int nslab,
+                                        int B, int64_t HW, int C, float eps, int act, float slope, int dtype, void* stream) {
+    UIG_CHECK_ARG(x && y && stats && partial && nslab > 0, "uig_instnorm_act_fwd_pre: null pointer");
+    UIG_CHECK_ARG(act == UIG_ACT_NONE || act == UIG_ACT_RELU || act == UIG_ACT_LRELU, "uig_instnorm_act_fwd_pre: bad act %d", act);
+    int CC; if (int r = check_in_args("uig_instnorm_act_fwd_pre", B, HW, C, dtype, &CC)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    const int na = apply_slabs(HW, CC);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 15) / 16), dim3(256), 0, s, partial, stats, B * C, C, nslab, 1.0 / (double)HW, eps, 0, 0, 0);
+    UIG_LAUNCH_CHECK("uig_instnorm_act_fwd_pre(finalize)");
+    if (dtype == UIG_BF16)
+        hipLaunchKernelGGL((in_apply_fwd_kernel<bf16_t>), dim3(na, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, stats, (long)HW, C, CC, na, act, slope);
+    else
+        hipLaunchKernelGGL((in_apply_fwd_kernel<float>), dim3(na, B), dim3(256), 0, s, (const float*)x, (const float*)residual, (float*)y, stats, (long)HW, C, CC, na, act, slope);
+    UIG_LAUNCH_CHECK("uig_instnorm_act_fwd_pre(apply)");
+    return 0;
+}
+
 extern "C" int uig_instnorm_act_bwd(const void* dy, const void* x, const float* stats, void* dx, float* workspace,
                                     int B, int64_t HW, int C, int act, float slope, int dtype, void* stream) {
     return instnorm_bwd_impl(dy, x, stats, dx, workspace, nullptr, B, HW, C, act, slope, dtype, stream);

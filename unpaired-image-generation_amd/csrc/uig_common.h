@@ -80,10 +80,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 // scratch as [pixel][channel] rows with a 16-byte-chunk XOR swizzle, then reads it back row-wise so that consecutive
 // lanes hold consecutive 16-byte chunks of one pixel and every store instruction writes whole 128/256-byte rows.
 // row_ptr(r) returns the output pointer of tile row r (pixel) at channel 0 of this wave's 64 channels, or nullptr.
+// stat_out (optional, wave-uniform): fp32[64][2] slot of the InstanceNorm partial-statistics buffer for this wave's 64
+// channels; receives (sum, sum of squares) over the first nvalid pixel rows of the tile AS STORED (rounded to T), so the
+// separate statistics pass of the following InstanceNorm disappears.
 template <typename T, int MT, int NT, typename RowPtr>
 __device__ __forceinline__ void store_tile_via_lds(const f32x4_t (&acc)[NT][MT], unsigned char* scratch, int lane,
                                                    const float* bias4 /* NT*4 bias values of this lane, or nullptr */,
-                                                   int act, float slope, RowPtr row_ptr) {
+                                                   int act, float slope, RowPtr row_ptr, float* stat_out = nullptr,
+                                                   int nvalid = 64) {
     static_assert(MT == 4 && NT == 4, "64 x 64 wave tile");
     constexpr int ROWB = 64 * (int)sizeof(T);          // 128 (bf16) / 256 (f32) bytes per pixel row
     constexpr int NCH = ROWB / 16;                     // 16-byte chunks per row
@@ -117,6 +121,15 @@ __device__ __forceinline__ void store_tile_via_lds(const f32x4_t (&acc)[NT][MT],
         T* dst = row_ptr(r);
         const u32x4_t val = *reinterpret_cast<const u32x4_t*>(scratch + r * ROWB + ((c ^ (r & (NCH - 1))) * 16));
         if (dst != nullptr) *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(dst) + c * 16) = val;
+    }
+    if (stat_out != nullptr) {                         // lane <-> channel: column sums over the tile's pixel rows
+        const int cb = lane * (int)sizeof(T);          // byte offset of this lane's channel inside an unswizzled row
+        float s1 = 0.f, s2 = 0.f;
+        for (int r = 0; r < nvalid; ++r) {
+            const float v = ElemTraits<T>::ld(reinterpret_cast<const T*>(scratch + r * ROWB + (((cb >> 4) ^ (r & (NCH - 1))) << 4) + (cb & 15)));
+            s1 += v; s2 += v * v;
+        }
+        stat_out[lane * 2] = s1; stat_out[lane * 2 + 1] = s2;
     }
 }
 

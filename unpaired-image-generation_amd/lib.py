@@ -27,6 +27,7 @@ SIGNATURES = {
     "uig_debug_set_strip_stamps": (None, [_vp]),
     "uig_conv_gather": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_i, _f, _i, _vp]),
     "uig_conv_gather_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp] + [_i] * 15 + [_i, _f, _i, _vp]),
+    "uig_conv_gather_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp] + [_i] * 15 + [_i, _f, _i, _vp]),
     "uig_wgrad_workspace_bytes": (_sz, [_i] * 5),
     "uig_wgrad_partial": (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp]),
     "uig_wgrad_reduce": (_i, [_vp, _vp] + [_i] * 7 + [_vp]),
@@ -35,6 +36,7 @@ SIGNATURES = {
     "uig_pack_weight": (_i, [_vp, _vp] + [_i] * 9 + [_vp]),
     "uig_instnorm_workspace_floats": (_sz, [_i, _i64, _i]),
     "uig_instnorm_act_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _i, _f, _i, _vp]),
+    "uig_instnorm_act_fwd_pre": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _f, _i, _f, _i, _vp]),
     "uig_instnorm_act_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _vp]),
     "uig_instnorm_bwd_colsum_slabs": (_i, [_i, _i64, _i, _i]),
     "uig_instnorm_act_bwd_colsum": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _vp]),

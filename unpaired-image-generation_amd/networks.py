@@ -46,6 +46,7 @@ class ConvLayer(nn.Module):
         self.register_buffer("wp_dgrad", torch.zeros(sd, device=device, dtype=dtype), persistent=False)
         self._packed_version = None
         self.fuse_grad_accum = True    # backward adds dW/db into an existing .grad in place (see ops.ConvFn.backward)
+        self.emit_in_stats = False     # set by the network builders for convs that feed an InstanceNorm
 
     def repack(self):
         ops.pack_weights(self.spec, self.weight.data, self.compute_dtype, self.wp_fwd, self.wp_dgrad)
@@ -116,6 +117,19 @@ class _PhysNet(nn.Sequential):
     def conv_layers(self):
         return [m for m in self.modules() if isinstance(m, ConvLayer)]
 
+    def _mark_in_producers(self):
+        """convolutions directly followed by an InstanceNorm accumulate its statistics in their epilogue"""
+        def walk(seq):
+            mods = list(seq)
+            for a, b in zip(mods, mods[1:]):
+                if isinstance(a, ConvLayer) and isinstance(b, InstNormAct):
+                    a.emit_in_stats = True
+                if isinstance(a, ResBlock):
+                    walk(a.b)
+            if mods and isinstance(mods[-1], ResBlock):
+                walk(mods[-1].b)
+        walk(self)
+
     def repack(self):
         for m in self.conv_layers():
             m.repack()
@@ -137,6 +151,7 @@ class Generator(_PhysNet):
                  ConvLayer("conv", ngf, out_ch, 7, 1, 3, "reflect", act=L.ACT_TANH, **kw), _Slot("Tanh -> conv epilogue")]
         super().__init__(*mods)
         self.in_ch, self.out_ch, self.compute_dtype = in_ch, out_ch, dtype
+        self._mark_in_producers()
 
 
 class Discriminator(_PhysNet):
@@ -154,6 +169,7 @@ class Discriminator(_PhysNet):
         mods += [ConvLayer("conv", ndf * nf, 1, 4, 1, 1, **kw)]
         super().__init__(*mods)
         self.in_ch, self.out_ch, self.compute_dtype = in_ch, 1, dtype
+        self._mark_in_producers()
 
 
 def pair_forward_phys(net1: _PhysNet, net2: _PhysNet, x: torch.Tensor) -> torch.Tensor:

@@ -136,10 +136,16 @@ def packed_shapes(spec: ConvSpec):
     return (spec.cout, t, spec.cin_p), (spec.cin, t, spec.cout_p)
 
 
-def _gather(x, wp, bias, y, B, H, W, C, nrows, spec, stride, pad, pm, mode, Ho, Wo, ldc, act, slope, what, pair=None):
-    """one uig_conv_gather launch; pair = (wp2, bias2, group_images) makes it a two-network launch"""
+def _gather(x, wp, bias, y, B, H, W, C, nrows, spec, stride, pad, pm, mode, Ho, Wo, ldc, act, slope, what, pair=None,
+            in_partial=None):
+    """one uig_conv_gather launch; pair = (wp2, bias2, group_images) makes it a two-network launch; in_partial receives the
+    fused InstanceNorm statistics partials"""
     lib = L.lib()
-    if pair is None:
+    if in_partial is not None:
+        wp2, bias2, g = pair if pair is not None else (None, None, 0)
+        rc = lib.uig_conv_gather_ex(_p(x), _p(wp), _p(bias), _p(wp2), _p(bias2), g, _p(in_partial), _p(y), B, H, W, C, nrows,
+                                    spec.k, spec.k, stride, pad, pm, mode, Ho, Wo, ldc, ldc, act, slope, _dt(x), _stream())
+    elif pair is None:
         rc = lib.uig_conv_gather(_p(x), _p(wp), _p(bias), _p(y), B, H, W, C, nrows, spec.k, spec.k, stride, pad, pm, mode,
                                  Ho, Wo, ldc, ldc, act, slope, _dt(x), _stream())
     else:
@@ -149,7 +155,17 @@ def _gather(x, wp, bias, y, B, H, W, C, nrows, spec, stride, pad, pm, mode, Ho, 
     L.check(rc, what)
 
 
-def conv_forward(spec: ConvSpec, x: torch.Tensor, wp_fwd: torch.Tensor, bias: torch.Tensor | None, pair=None) -> torch.Tensor:
+def in_stats_fusable(spec: ConvSpec, H: int, W: int) -> bool:
+    """can this layer's forward launch also emit the statistics of the InstanceNorm that follows it? (rule of uig_conv_gather_ex)"""
+    Ho, Wo = spec.out_hw(H, W)
+    grid = Ho * Wo if spec.kind == "conv" else (Ho // spec.stride) * (Wo // spec.stride)
+    return spec.cout > 64 and spec.cout % 64 == 0 and grid % 64 == 0 and spec.act == L.ACT_NONE
+
+
+def conv_forward(spec: ConvSpec, x: torch.Tensor, wp_fwd: torch.Tensor, bias: torch.Tensor | None, pair=None,
+                 want_in_stats: bool = False) -> torch.Tensor:
+    """want_in_stats: also accumulate the following InstanceNorm's (sum, sum^2) partials in the epilogue; they travel to
+    ops.InstNormActFn as the attribute `_uig_in_partial` of the returned tensor."""
     _chk_phys(x, "conv_forward")
     B, H, W, C = x.shape
     if C != spec.cin_p:
@@ -160,8 +176,14 @@ def conv_forward(spec: ConvSpec, x: torch.Tensor, wp_fwd: torch.Tensor, bias: to
         mode, pm = L.GATHER_DIRECT, (L.PAD_REFLECT if spec.reflect else L.PAD_ZERO)
     else:
         mode, pm = L.GATHER_TRANSPOSED, L.PAD_ZERO
+    part = None
+    if want_in_stats and in_stats_fusable(spec, H, W):
+        nslab = Ho * Wo // 64
+        part = torch.empty((B * nslab * spec.cout_store * 2,), device=x.device, dtype=torch.float32)
     _gather(x, wp_fwd, bias, y, B, H, W, C, spec.cout, spec, spec.stride, spec.pad, pm, mode, Ho, Wo, spec.cout_store,
-            spec.act, spec.slope, "uig_conv_gather(fwd)", pair)
+            spec.act, spec.slope, "uig_conv_gather(fwd)", pair, part)
+    if part is not None:
+        y._uig_in_partial = (part, Ho * Wo // 64)
     return y
 
 
@@ -323,7 +345,7 @@ class ConvFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, layer):
         spec = layer.spec
-        y = conv_forward(spec, x, layer.wp_fwd, bias)
+        y = conv_forward(spec, x, layer.wp_fwd, bias, want_in_stats=layer.emit_in_stats)
         ctx.layer, ctx.in_hw = layer, (x.shape[1], x.shape[2])
         ctx.save_for_backward(x, y if spec.act != L.ACT_NONE else None)
         return y
@@ -341,7 +363,7 @@ class PairConvFn(Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, layer1, layer2, group):
         spec = layer1.spec
-        y = conv_forward(spec, x, layer1.wp_fwd, b1, pair=(layer2.wp_fwd, b2, group))
+        y = conv_forward(spec, x, layer1.wp_fwd, b1, pair=(layer2.wp_fwd, b2, group), want_in_stats=layer1.emit_in_stats)
         ctx.layers, ctx.group, ctx.in_hw = (layer1, layer2), group, (x.shape[1], x.shape[2])
         ctx.save_for_backward(x, y if spec.act != L.ACT_NONE else None)
         return y
@@ -361,8 +383,13 @@ class InstNormActFn(Function):
         ws = torch.empty((int(lib.uig_instnorm_workspace_floats(B, H * W, C)),), device=x.device, dtype=torch.float32)
         stats = torch.empty((B, C, 2), device=x.device, dtype=torch.float32)
         y = torch.empty_like(x)
-        L.check(lib.uig_instnorm_act_fwd(_p(x), _p(residual), _p(y), _p(stats), _p(ws), B, H * W, C, eps, act, slope,
-                                         _dt(x), _stream()), "uig_instnorm_act_fwd")
+        pre = getattr(x, "_uig_in_partial", None)
+        if pre is not None and pre[0].numel() == B * pre[1] * C * 2:      # statistics already accumulated by the conv epilogue
+            L.check(lib.uig_instnorm_act_fwd_pre(_p(x), _p(residual), _p(y), _p(stats), _p(pre[0]), pre[1], B, H * W, C, eps, act,
+                                                 slope, _dt(x), _stream()), "uig_instnorm_act_fwd_pre")
+        else:
+            L.check(lib.uig_instnorm_act_fwd(_p(x), _p(residual), _p(y), _p(stats), _p(ws), B, H * W, C, eps, act, slope,
+                                             _dt(x), _stream()), "uig_instnorm_act_fwd")
         ctx.act, ctx.slope, ctx.has_res = act, slope, residual is not None
         ctx.save_for_backward(x, stats)
         return y
@@ -370,20 +397,25 @@ class InstNormActFn(Function):
     @staticmethod
     def backward(ctx, dy):
         x, stats = ctx.saved_tensors
-        dy = dy.contiguous()
-        B, H, W, C = x.shape
-        lib = L.lib()
-        ws = torch.empty((int(lib.uig_instnorm_workspace_floats(B, H * W, C)),), device=x.device, dtype=torch.float32)
-        dx = torch.empty_like(x)
-        # dx is the gradient of the convolution output in front of this norm: its per-channel column sums are that conv's
-        # bias gradient.  The apply kernel emits them as per-block partials (no second pass over dx); the conv backward
-        # picks them up through the attribute below (same tensor object: the conv output feeds only this norm).
-        slabs = int(lib.uig_instnorm_bwd_colsum_slabs(B, H * W, C, _dt(x)))
-        cpart = torch.empty((slabs * C * 2,), device=x.device, dtype=torch.float32)
-        L.check(lib.uig_instnorm_act_bwd_colsum(_p(dy), _p(x), _p(stats), _p(dx), _p(ws), _p(cpart), B, H * W, C, ctx.act,
-                                                ctx.slope, _dt(x), _stream()), "uig_instnorm_act_bwd_colsum")
-        dx._uig_colsum = (cpart, slabs // B, C)
+        dx = instnorm_backward(dy.contiguous(), x, stats, ctx.act, ctx.slope)
         return dx, (dy if ctx.has_res else None), None, None, None
+
+
+def instnorm_backward(dy, x, stats, act, slope):
+    """dx of InstanceNorm(+activation).  dx is also the gradient of the convolution output in front of the norm: its
+    per-channel column sums are that conv's bias gradient.  The apply kernel emits them as per-block partials (no second
+    pass over dx); the conv backward picks them up through the attribute `_uig_colsum` (same tensor object: the conv
+    output feeds only this norm)."""
+    B, H, W, C = x.shape
+    lib = L.lib()
+    ws = torch.empty((int(lib.uig_instnorm_workspace_floats(B, H * W, C)),), device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x)
+    slabs = int(lib.uig_instnorm_bwd_colsum_slabs(B, H * W, C, _dt(x)))
+    cpart = torch.empty((slabs * C * 2,), device=x.device, dtype=torch.float32)
+    L.check(lib.uig_instnorm_act_bwd_colsum(_p(dy), _p(x), _p(stats), _p(dx), _p(ws), _p(cpart), B, H * W, C, act, slope,
+                                            _dt(x), _stream()), "uig_instnorm_act_bwd_colsum")
+    dx._uig_colsum = (cpart, slabs // B, C)
+    return dx
 
 
 # ----------------------------------------------------------------------------------------- fused losses
