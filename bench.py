@@ -109,9 +109,17 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch, S)
         print(json.dumps(out), flush=True)
+    # orderly shutdown, then skip interpreter teardown: destroying captured HIP graphs / the RCCL communicator from Python
+    # finalizers in arbitrary order has been seen to abort at exit after the result line was already printed
+    torch.cuda.synchronize(dev)
     if dist.is_initialized():
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:      # noqa: BLE001 - shutdown only
+            print(f"[bench] process-group shutdown: {e}", file=sys.stderr)
+    sys.stdout.flush(); sys.stderr.flush()
+    os._exit(0)
 
 
 def dominant_kernel_roofline(u, torch, dev, dtype, nimg, hw, iters):
