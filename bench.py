@@ -119,7 +119,9 @@ def main():
         except Exception as e:      # noqa: BLE001 - shutdown only
             print(f"[bench] process-group shutdown: {e}", file=sys.stderr)
     sys.stdout.flush(); sys.stderr.flush()
-    os._exit(0)
+    profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if not profiled and not os.environ.get("UIG_BENCH_SOFT_EXIT"):     # a profiler needs the normal atexit path to write its output
+        os._exit(0)
 
 
 def dominant_kernel_roofline(u, torch, dev, dtype, nimg, hw, iters):
