@@ -64,12 +64,21 @@ int uig_conv_gather_pair(const void* x, const void* wp, const float* bias, const
 
 /* Superset entry: optional second network (wp2 != NULL) and optional fused InstanceNorm statistics: in_partial
  * (fp32[B * (Ho*Wo/64) * Nstore * 2]) receives per-64-pixel (sum, sum of squares) of the stored output per channel, consumed by
- * uig_instnorm_act_fwd_pre.  Needs Nrows a multiple of 64 (> 64), Nstore == Nrows and (gather grid) % 64 == 0. */
+ * uig_instnorm_act_fwd_pre.  Needs Nrows a multiple of 64 (> 64), Nstore == Nrows and (gather grid) % 64 == 0.
+ * border_add (optional, strip kernel only: uig_conv_strip_applicable): the compact border buffer of
+ * uig_reflect3x3_dgrad_border, added to output rows 1 / H-2 and columns 1 / W-2 in the epilogue. */
 int uig_conv_gather_ex(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2,
-                       int group_images, float* in_partial, void* y,
+                       int group_images, float* in_partial, const void* border_add, void* y,
                        int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
                        int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
                        int act, float slope, int dtype, void* stream);
+
+/* Input gradient of a reflection-padded (pad 1) 3x3 stride-1 conv WITHOUT the padded (H+2)x(W+2) gradient + fold:
+ * this computes the mirrored-border terms (8 groups: top/bottom/left/right lines + 4 corners) into bord[B][8][H][ldc];
+ * then uig_conv_gather_ex(dy, ..., transposed, pad=1, zero, border_add=bord) produces dx on the exact HxW grid. */
+int uig_reflect3x3_dgrad_border(const void* dy, const void* wp, const void* wp2, int group_images, void* bord,
+                                int B, int H, int W, int C, int Nrows, int ldc, int dtype, void* stream);
+int uig_conv_strip_applicable(int B, int H, int W, int Cin, int Nrows, int Ho, int Wo, int dh_min, int dh_max, int dtype);
 
 /* aten::convolution_backward(weight grad) — dW partials by split-K MFMA GEMM over pixels, then uig_wgrad_reduce.
  *   part[s][n][tap][c] = sum_{pixels m in split s} P[m][n] * Q[pix(m,tap)][c]

@@ -30,7 +30,9 @@ CONV_CASES = [
     ("conv", 3, 64, 7, 1, 3, "reflect", 20, 24, 2),     # G layer 1 (Cin=3 -> small-Cin gather)
     ("conv", 64, 128, 3, 2, 1, "zero", 24, 20, 2),      # G downsample
     ("conv", 128, 256, 3, 2, 1, "zero", 12, 16, 1),
-    ("conv", 256, 256, 3, 1, 1, "reflect", 12, 10, 3),  # ResBlock conv (the 88 % shape), ragged M
+    ("conv", 256, 256, 3, 1, 1, "reflect", 12, 10, 3),  # ResBlock conv (the 88 % shape), ragged M, padded-gradient + fold dgrad
+    ("conv", 256, 256, 3, 1, 1, "reflect", 16, 16, 3),  # square map: strip kernel + direct dgrad with the border-term GEMM
+    ("conv", 128, 256, 3, 1, 1, "reflect", 64, 64, 2),  # the benchmark's 64x64 map (256-pixel strip tiles)
     ("convT", 256, 128, 3, 2, 1, "zero", 6, 8, 2),      # upsample
     ("convT", 128, 64, 3, 2, 1, "zero", 10, 6, 1),
     ("conv", 64, 3, 7, 1, 3, "reflect", 18, 22, 2),     # G head (Cout=3 -> BN=16 tile)
@@ -42,7 +44,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"{c[0]}{c[1]}-{c[2]}k{c[3]}s{c[4]}{c[6][0]}")
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"{c[0]}{c[1]}-{c[2]}k{c[3]}s{c[4]}{c[6][0]}{c[7]}")
 def test_conv_fwd_bwd(case, dtype):
     u, ops, networks = _mods()
     kind, cin, cout, k, s, p, pm, H, W, B = case

@@ -27,8 +27,10 @@ struct GatherDesc {
     int cin_shift;
     unsigned x_bytes, w_bytes;   // buffer sizes for the hardware range check
     int nphase;
-    int ph_tap0[5];
-    signed char ph_oh[4], ph_ow[4];
+    int ph_tap0[9];
+    signed char ph_oh[8], ph_ow[8];
+    unsigned char ph_swap[8];   // phase iterates its grid transposed: (ii, jj) <- (jj, ii)   (border-line launches)
+    int compact_out;            // output row = (image * nphase + phase) * Mh*Mw + ii*Mw + jj  instead of the (ho, wo) map
     int tap[64];           // per tap: (dh + 128) | (dw + 128) << 8 | weight-tap-index << 16  (one scalar dword load)
     const void* wp2;       // paired launch: GEMM rows >= group_rows (the second network's images) use wp2 / bias2
     const float* bias2;
@@ -98,7 +100,9 @@ void igemm_kernel(const T* __restrict__ x, const T* __restrict__ wp_, const floa
         const int m = m_base + lr + RPP * i;
         const bool v = m < M;
         const int mm = v ? m : 0;
-        const int jj = mm % d.Mw, t = mm / d.Mw, ii = t % d.Mh, b = t / d.Mh;
+        const int jj0 = mm % d.Mw, t = mm / d.Mw, ii0 = t % d.Mh, b = t / d.Mh;
+        const bool sw = d.ph_swap[blockIdx.y] != 0;
+        const int ii = sw ? jj0 : ii0, jj = sw ? ii0 : jj0;
         hb[i] = ii * d.si; wb[i] = jj * d.si; ib[i] = b * d.H * d.W;
         vmask |= (v ? 1u : 0u) << i;
     }
@@ -242,6 +246,7 @@ void igemm_kernel(const T* __restrict__ x, const T* __restrict__ wp_, const floa
     auto out_row = [&](int m) -> T* {                 // output pointer (channel 0) of GEMM row m, nullptr if not stored
         if (m >= M) return nullptr;
         const int jj = m % d.Mw, t = m / d.Mw, ii = t % d.Mh, bb = t / d.Mh;
+        if (d.compact_out) return y + ((long)(bb * d.nphase + ph) * (d.Mh * d.Mw) + ii * d.Mw + jj) * d.ldc;
         const int ho = ii * d.so + oh0, wo = jj * d.so + ow0;
         if (ho >= d.Ho || wo >= d.Wo) return nullptr;
         return y + ((long)(bb * d.Ho + ho) * d.Wo + wo) * d.ldc;
@@ -353,14 +358,14 @@ static int dispatch_igemm(const void* x, const void* wp, const float* bias, void
 }
 
 int uig_try_conv_strip(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
-                       float* in_partial, void* y, int B, int H, int W, int Cin, int Nrows,
+                       float* in_partial, const void* border_add, void* y, int B, int H, int W, int Cin, int Nrows,
                        int k, int pad_mode, const int* taps, int ntaps, int dh_min, int dh_max, int Ho, int Wo, int ldc, int Nstore,
                        int act, float slope, int dtype, long x_bytes, long w_bytes, hipStream_t s, int* rc_out);
 
 static int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
 static int conv_gather_impl(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
-                            float* in_partial, void* y, int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
+                            float* in_partial, const void* border_add, void* y, int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
                             int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
                             int act, float slope, int dtype, void* stream) {
     UIG_CHECK_ARG(x && wp && y, "uig_conv_gather: null pointer");
@@ -429,20 +434,21 @@ static int conv_gather_impl(const void* x, const void* wp, const float* bias, co
     if (d.nphase == 1 && stride == 1 && kH == kW) {      // stride-1 k x k: LDS-resident input strip kernel (conv_strip.hip)
         int dmin = 127, dmax = -127, rc = 0;
         for (int t = 0; t < kH * kW; ++t) { const int dh = (d.tap[t] & 255) - 128; dmin = std::min(dmin, dh); dmax = std::max(dmax, dh); }
-        if (uig_try_conv_strip(x, wp, bias, wp2, bias2, group_images, in_partial, y, B, H, W, Cin, Nrows, kH, pad_mode, d.tap, kH * kW, dmin, dmax,
+        if (uig_try_conv_strip(x, wp, bias, wp2, bias2, group_images, in_partial, border_add, y, B, H, W, Cin, Nrows, kH, pad_mode, d.tap, kH * kW, dmin, dmax,
                                Ho, Wo, ldc, Nstore, act, slope, dtype, (long)d.x_bytes, (long)d.w_bytes, s, &rc))
             return rc;
     }
+    UIG_CHECK_ARG(border_add == nullptr, "uig_conv_gather_ex: border_add needs the stride-1 3x3 strip kernel (query uig_conv_strip_applicable)");
     if (wp2 != nullptr) {
         const long grows = (long)group_images * d.Mh * d.Mw;
         if (grows % 256 != 0) {      // a tile could straddle the two groups: run them as two launches (same results)
             const long esz2 = dtype == UIG_BF16 ? 2 : 4;
             const long pstride = (long)(Ho * Wo / 64) * Nstore * 2;
-            int rc = conv_gather_impl(x, wp, bias, nullptr, nullptr, 0, in_partial, y, group_images, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode,
+            int rc = conv_gather_impl(x, wp, bias, nullptr, nullptr, 0, in_partial, nullptr, y, group_images, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode,
                                       gather_mode, Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
             if (rc) return rc;
             return conv_gather_impl((const char*)x + (long)group_images * H * W * Cin * esz2, wp2, bias2, nullptr, nullptr, 0,
-                                    in_partial ? in_partial + group_images * pstride : nullptr, (char*)y + (long)group_images * Ho * Wo * ldc * esz2, B - group_images, H, W, Cin, Nrows, kH, kW,
+                                    in_partial ? in_partial + group_images * pstride : nullptr, nullptr, (char*)y + (long)group_images * Ho * Wo * ldc * esz2, B - group_images, H, W, Cin, Nrows, kH, kW,
                                     stride, pad, pad_mode, gather_mode, Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
         }
         d.wp2 = wp2; d.bias2 = bias2; d.group_rows = (int)grows;
@@ -454,7 +460,7 @@ extern "C" int uig_conv_gather(const void* x, const void* wp, const float* bias,
                                int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
                                int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
                                int act, float slope, int dtype, void* stream) {
-    return conv_gather_impl(x, wp, bias, nullptr, nullptr, 0, nullptr, y, B, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode, gather_mode,
+    return conv_gather_impl(x, wp, bias, nullptr, nullptr, 0, nullptr, nullptr, y, B, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode, gather_mode,
                             Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
 }
 
@@ -464,15 +470,72 @@ extern "C" int uig_conv_gather_pair(const void* x, const void* wp, const float* 
                                     int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
                                     int act, float slope, int dtype, void* stream) {
     UIG_CHECK_ARG(wp2 != nullptr, "uig_conv_gather_pair: null wp2");
-    return conv_gather_impl(x, wp, bias, wp2, bias2, group_images, nullptr, y, B, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode, gather_mode,
+    return conv_gather_impl(x, wp, bias, wp2, bias2, group_images, nullptr, nullptr, y, B, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode, gather_mode,
                             Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
 }
 
 extern "C" int uig_conv_gather_ex(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2,
-                                  int group_images, float* in_partial, void* y,
+                                  int group_images, float* in_partial, const void* border_add, void* y,
                                   int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
                                   int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
                                   int act, float slope, int dtype, void* stream) {
-    return conv_gather_impl(x, wp, bias, wp2, bias2, wp2 ? group_images : 0, in_partial, y, B, H, W, Cin, Nrows, kH, kW, stride, pad,
+    return conv_gather_impl(x, wp, bias, wp2, bias2, wp2 ? group_images : 0, in_partial, border_add, y, B, H, W, Cin, Nrows, kH, kW, stride, pad,
                             pad_mode, gather_mode, Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Border terms of the input gradient of a reflection-padded (pad 1) 3x3 stride-1 convolution.
+//   dx = zero-pad-1 transposed conv of dy   (exact 64x64-style grid: perfect tile rounds, conv_strip.hip)
+//      + terms whose padded coordinate was mirrored:
+//        T: dx[1][j]   += sum_kw dy[0][j+1-kw]   W[0][kw]      B: dx[H-2][j] += sum_kw dy[H-1][j+1-kw] W[2][kw]
+//        L: dx[i][1]   += sum_kh dy[i+1-kh][0]   W[kh][0]      R: dx[i][W-2] += sum_kh dy[i+1-kh][W-1] W[kh][2]
+//        corners: dx[1][1] += dy[0][0] W[0][0], dx[1][W-2] += dy[0][W-1] W[0][2], dx[H-2][1] += dy[H-1][0] W[2][0],
+//                 dx[H-2][W-2] += dy[H-1][W-1] W[2][2]
+// This launch computes those 8 groups as 8 phases of the generic gather kernel into the compact buffer
+// bord[B][8][S][ldc] (S = H = W; corner phases use position 0 only); the strip kernel's epilogue adds them
+// (border_add of uig_conv_gather_ex).  Replaces the (H+2)x(W+2) padded gradient + uig_reflect_fold.
+extern "C" int uig_reflect3x3_dgrad_border(const void* dy, const void* wp, const void* wp2, int group_images, void* bord,
+                                           int B, int H, int W, int C, int Nrows, int ldc, int dtype, void* stream) {
+    UIG_CHECK_ARG(dy && wp && bord, "uig_reflect3x3_dgrad_border: null pointer");
+    UIG_CHECK_ARG(H == W && H >= 4 && H <= 128, "uig_reflect3x3_dgrad_border: needs a square map of side 4..128 (got %dx%d)", H, W);
+    UIG_CHECK_ARG(C % 8 == 0 && Nrows >= 1 && Nrows <= ldc, "uig_reflect3x3_dgrad_border: bad channels C=%d Nrows=%d ldc=%d", C, Nrows, ldc);
+    UIG_CHECK_ARG(dtype == UIG_F32 || dtype == UIG_BF16, "uig_reflect3x3_dgrad_border: bad dtype");
+    const int BKe = dtype == UIG_BF16 ? 64 : 32;
+    UIG_CHECK_ARG(C % BKe == 0, "uig_reflect3x3_dgrad_border: C=%d must be a multiple of %d", C, BKe);
+    const long esz = dtype == UIG_BF16 ? 2 : 4;
+    GatherDesc d{};
+    d.B = B; d.H = H; d.W = W; d.Cin = C; d.pad_mode = UIG_PAD_ZERO;
+    d.Nrows = Nrows; d.ldw = 9 * C; d.Ho = 1; d.Wo = 1; d.ldc = ldc; d.Nstore = ldc; d.act = UIG_ACT_NONE; d.slope = 0.f;
+    d.cin_shift = 0; while ((1 << d.cin_shift) < C) ++d.cin_shift;
+    d.x_bytes = (unsigned)((long)B * H * W * C * esz); d.w_bytes = (unsigned)((long)Nrows * 9 * C * esz);
+    d.nphase = 8; d.si = 1; d.so = 1; d.Mh = 1; d.Mw = H; d.compact_out = 1;
+    auto tap = [](int dh, int dw, int wt) { return (dh + 128) | ((dw + 128) << 8) | (wt << 16); };
+    int nt = 0;
+    // T, B (position = column)
+    d.ph_tap0[0] = nt; for (int kw = 0; kw < 3; ++kw) d.tap[nt++] = tap(0, 1 - kw, 0 * 3 + kw);
+    d.ph_tap0[1] = nt; for (int kw = 0; kw < 3; ++kw) d.tap[nt++] = tap(H - 1, 1 - kw, 2 * 3 + kw);
+    // L, R (position = row: swapped iteration)
+    d.ph_tap0[2] = nt; d.ph_swap[2] = 1; for (int kh = 0; kh < 3; ++kh) d.tap[nt++] = tap(1 - kh, 0, kh * 3 + 0);
+    d.ph_tap0[3] = nt; d.ph_swap[3] = 1; for (int kh = 0; kh < 3; ++kh) d.tap[nt++] = tap(1 - kh, W - 1, kh * 3 + 2);
+    // corners (position 0 is the value; other positions are never read)
+    d.ph_tap0[4] = nt; d.tap[nt++] = tap(0, 0, 0);
+    d.ph_tap0[5] = nt; d.tap[nt++] = tap(0, W - 1, 2);
+    d.ph_tap0[6] = nt; d.tap[nt++] = tap(H - 1, 0, 6);
+    d.ph_tap0[7] = nt; d.tap[nt++] = tap(H - 1, W - 1, 8);
+    d.ph_tap0[8] = nt;
+    if (wp2 != nullptr) {
+        UIG_CHECK_ARG(group_images > 0 && group_images < B, "uig_reflect3x3_dgrad_border: bad group_images");
+        const long grows = (long)group_images * H;
+        if (grows % 256 != 0) {       // tiles could straddle the groups: two launches
+            int rc = uig_reflect3x3_dgrad_border(dy, wp, nullptr, 0, bord, group_images, H, W, C, Nrows, ldc, dtype, stream);
+            if (rc) return rc;
+            return uig_reflect3x3_dgrad_border((const char*)dy + (long)group_images * H * W * C * esz, wp2, nullptr, 0,
+                                               (char*)bord + (long)group_images * 8 * H * ldc * esz, B - group_images, H, W, C, Nrows,
+                                               ldc, dtype, stream);
+        }
+        d.wp2 = wp2; d.bias2 = nullptr; d.group_rows = (int)grows;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == UIG_BF16 ? dispatch_igemm<bf16_t>(dy, wp, nullptr, bord, d, s) : dispatch_igemm<float>(dy, wp, nullptr, bord, d, s);
 }

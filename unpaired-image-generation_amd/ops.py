@@ -8,6 +8,7 @@ streams and autograd bookkeeping only; every FLOP on these paths runs in libuig.
 from __future__ import annotations
 
 import contextlib
+import os
 
 import torch
 from torch.autograd import Function
@@ -15,7 +16,8 @@ from torch.autograd import Function
 from . import lib as L
 
 
-PARALLEL_BACKWARD = True      # run a conv's parameter-gradient kernels concurrently with its input-gradient kernel
+REFLECT_DGRAD_DIRECT = os.environ.get("UIG_REFLECT_DGRAD_DIRECT", "1") != "0"   # 3x3 reflect-pad convs: input gradient on the exact grid + border GEMM (no padded gradient, no fold)
+PARALLEL_BACKWARD = os.environ.get("UIG_PARALLEL_BACKWARD", "1") != "0"      # run a conv's parameter-gradient kernels concurrently with its input-gradient kernel
 _SIDE_STREAMS = {}
 
 
@@ -137,13 +139,13 @@ def packed_shapes(spec: ConvSpec):
 
 
 def _gather(x, wp, bias, y, B, H, W, C, nrows, spec, stride, pad, pm, mode, Ho, Wo, ldc, act, slope, what, pair=None,
-            in_partial=None):
+            in_partial=None, border_add=None):
     """one uig_conv_gather launch; pair = (wp2, bias2, group_images) makes it a two-network launch; in_partial receives the
     fused InstanceNorm statistics partials"""
     lib = L.lib()
-    if in_partial is not None:
+    if in_partial is not None or border_add is not None:
         wp2, bias2, g = pair if pair is not None else (None, None, 0)
-        rc = lib.uig_conv_gather_ex(_p(x), _p(wp), _p(bias), _p(wp2), _p(bias2), g, _p(in_partial), _p(y), B, H, W, C, nrows,
+        rc = lib.uig_conv_gather_ex(_p(x), _p(wp), _p(bias), _p(wp2), _p(bias2), g, _p(in_partial), _p(border_add), _p(y), B, H, W, C, nrows,
                                     spec.k, spec.k, stride, pad, pm, mode, Ho, Wo, ldc, ldc, act, slope, _dt(x), _stream())
     elif pair is None:
         rc = lib.uig_conv_gather(_p(x), _p(wp), _p(bias), _p(y), B, H, W, C, nrows, spec.k, spec.k, stride, pad, pm, mode,
@@ -204,6 +206,20 @@ def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, 
         dx = torch.empty((B, H, W, spec.cin_p), device=dy.device, dtype=dy.dtype)
         _gather(dy, wp_dgrad, None, dx, B, Ho, Wo, Cd, spec.cin, spec, spec.stride, spec.pad, L.PAD_ZERO, L.GATHER_DIRECT, H, W,
                 spec.cin_p, L.ACT_NONE, 0.0, "uig_conv_gather(convT dgrad)", pair)
+        return dx
+    if spec.reflect and spec.k == 3 and spec.pad == 1 and spec.stride == 1 and H == W and 4 <= H <= 128 and REFLECT_DGRAD_DIRECT \
+            and L.lib().uig_conv_strip_applicable(B, Ho, Wo, Cd, spec.cin, H, W, -1, 1, _dt(dy)) == 1:
+        # pad-1 reflection, 3x3: dx on the exact H x W grid (zero-pad transposed conv: whole tile rounds on 256 CUs) plus the
+        # mirrored-border terms from one small 8-phase GEMM, added in the strip kernel's epilogue.  No (H+2)x(W+2)
+        # padded gradient, no fold kernel.
+        lib = L.lib()
+        bord = torch.empty((B, 8, H, spec.cin_p), device=dy.device, dtype=dy.dtype)
+        wp2, g = (pair[0], pair[2]) if pair is not None else (None, 0)
+        L.check(lib.uig_reflect3x3_dgrad_border(_p(dy), _p(wp_dgrad), _p(wp2), g, _p(bord), B, Ho, Wo, Cd, spec.cin, spec.cin_p,
+                                                _dt(dy), s), "uig_reflect3x3_dgrad_border")
+        dx = torch.empty((B, H, W, spec.cin_p), device=dy.device, dtype=dy.dtype)
+        _gather(dy, wp_dgrad, None, dx, B, Ho, Wo, Cd, spec.cin, spec, 1, 1, L.PAD_ZERO, L.GATHER_TRANSPOSED, H, W, spec.cin_p,
+                L.ACT_NONE, 0.0, "uig_conv_gather(dgrad+border)", pair, None, bord)
         return dx
     if spec.reflect:             # gradient w.r.t. the reflection-padded input, then fold the border back
         P = spec.pad
