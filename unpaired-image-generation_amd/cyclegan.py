@@ -16,6 +16,9 @@ MI355X-first choices (all result-preserving because InstanceNorm statistics are 
 """
 from __future__ import annotations
 
+import contextlib
+import os
+
 import torch
 
 from . import ops
@@ -38,6 +41,8 @@ class CycleGAN:
         self.xchg = GradExchange(process_group, force=force_exchange)
         self.world = self.xchg.world
         self.use_graph, self.batch_fused, self.paired = use_graph, batch_fused, paired
+        # parameter-gradient kernels stay on the side stream across layers and are joined once per phase (see ops.deferred_param_grads)
+        self.defer_join = os.environ.get("UIG_DEFER_JOIN", "1") != "0"
         self._graphs = None
         self._finalize_params()
 
@@ -104,7 +109,8 @@ class CycleGAN:
         l_cyc_A = ops.l1_loss(rec_A, xa, self.lam, n_real)
         l_cyc_B = ops.l1_loss(rec_B, xb, self.lam, n_real)
         losses = [l_idt_A, l_idt_B, l_G_A, l_G_B, l_cyc_A, l_cyc_B]
-        torch.autograd.backward(losses)
+        with ops.deferred_param_grads(self.device) if self.defer_join else contextlib.nullcontext():
+            torch.autograd.backward(losses)
         self.grp_D.set_requires_grad(True)
         self.last_fake_B = fake_B.detach()
         return fake_B.detach(), fake_A.detach(), losses
@@ -117,7 +123,8 @@ class CycleGAN:
             p = pair_forward_phys(self.D_A, self.D_B, torch.cat([xb, fake_B, xa, fake_A]))
             ls = [ops.mse_const(p[:B], 1.0, 0.5), ops.mse_const(p[B:2 * B], 0.0, 0.5),
                   ops.mse_const(p[2 * B:3 * B], 1.0, 0.5), ops.mse_const(p[3 * B:], 0.0, 0.5)]
-            torch.autograd.backward(ls)
+            with ops.deferred_param_grads(self.device) if self.defer_join else contextlib.nullcontext():
+                torch.autograd.backward(ls)
             return [(ls[0], ls[1]), (ls[2], ls[3])]
         for D, real, fake in ((self.D_A, xb, fake_B), (self.D_B, xa, fake_A)):
             if self.batch_fused:

@@ -19,6 +19,7 @@ from . import lib as L
 REFLECT_DGRAD_DIRECT = os.environ.get("UIG_REFLECT_DGRAD_DIRECT", "1") != "0"   # 3x3 reflect-pad convs: input gradient on the exact grid + border GEMM (no padded gradient, no fold)
 PARALLEL_BACKWARD = os.environ.get("UIG_PARALLEL_BACKWARD", "1") != "0"      # run a conv's parameter-gradient kernels concurrently with its input-gradient kernel
 _SIDE_STREAMS = {}
+_DEFER_JOIN = {}
 
 
 def _side_stream(device) -> torch.cuda.Stream:
@@ -27,6 +28,28 @@ def _side_stream(device) -> torch.cuda.Stream:
     if st is None:
         st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return st
+
+
+class deferred_param_grads:
+    """Context manager for a backward region whose parameter gradients are accumulated in place (trainer-owned flat
+    gradient buffers): inside it the conv backward does not join its side stream after every layer; on exit the main
+    stream waits for the side stream once.  Nothing inside the region may read the .grad buffers."""
+
+    def __init__(self, device):
+        self.idx = torch.device(device).index
+        if self.idx is None:
+            self.idx = torch.cuda.current_device()
+
+    def __enter__(self):
+        _DEFER_JOIN[self.idx] = True
+        return self
+
+    def __exit__(self, *exc):
+        _DEFER_JOIN[self.idx] = False
+        st = _SIDE_STREAMS.get(self.idx)
+        if st is not None:
+            torch.cuda.current_stream(self.idx).wait_stream(st)
+        return False
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -333,7 +356,9 @@ def _conv_backward(ctx, dy, layers, group):
     need_b = [ctx.needs_input_grad[2 + 2 * i] for i in range(npar)]
     any_p = any(need_w) or any(need_b)
     pair = None if npar == 1 else (layers[1].wp_dgrad, None, group)
-    par = need_x and any_p and PARALLEL_BACKWARD
+    fused_all = all(l.fuse_grad_accum and l.weight.grad is not None and l.bias.grad is not None for l in layers)
+    defer = _DEFER_JOIN.get(torch.device(dy.device).index, False) and any_p and fused_all and PARALLEL_BACKWARD
+    par = (need_x or defer) and any_p and PARALLEL_BACKWARD
     main = torch.cuda.current_stream(dy.device)
     dx = None
     if need_x and not par:
@@ -350,8 +375,17 @@ def _conv_backward(ctx, dy, layers, group):
                 xs, dys, i0 = (x[:group], dy[:group], 0) if i == 0 else (x[group:], dy[group:], group)
             grads.extend(_param_grads(layer, spec, xs, dys, need_w[i], need_b[i], colsum, i0))
     if par:
-        dx = conv_dgrad(spec, dy, layers[0].wp_dgrad, ctx.in_hw, pair)
-        main.wait_stream(side)
+        if need_x:
+            dx = conv_dgrad(spec, dy, layers[0].wp_dgrad, ctx.in_hw, pair)
+        if defer:
+            # no join here: the side stream keeps working behind the main stream's next ops (InstanceNorm backward, the next
+            # layer's input gradient, ...).  The tensors it reads are pinned for the allocator with record_stream; the owner
+            # of the deferred region joins once (join_param_grads) before anything consumes the .grad buffers.
+            x.record_stream(side); dy.record_stream(side)
+            if colsum is not None:
+                colsum[0].record_stream(side)
+        else:
+            main.wait_stream(side)
     return (dx, *grads)
 
 
