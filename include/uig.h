@@ -102,6 +102,11 @@ int uig_bias_grad(const void* dy, float* db, float* workspace, int64_t pixels, i
 int uig_pack_weight(const float* w, void* wp, int D0, int D1, int kH, int kW, int row_dim, int flip,
                     int rows_padded, int cols_padded, int dtype, void* stream);
 
+/* Every layer of every network in one launch.  items_dev: device array of nitems 48-byte records
+ * {const float* w; void* dst; int D0, D1, taps, row_dim, rows_padded, cols_padded; int64 work_end} where work_end is the
+ * inclusive prefix sum of rows_padded*taps*cols_padded; total_work = the last work_end. */
+int uig_pack_weights_multi(const void* items_dev, int nitems, int64_t total_work, int dtype, void* stream);
+
 /* aten::instance_norm(use_input_stats=True, weight=None, eps) fused with ReLU / LeakyReLU and residual add:
  *   y = act((x - mean_bc) * rstd_bc) + (residual ? residual : 0);  stats fp32[B*C*2] = (mean, rstd) saved for bwd.
  * workspace: fp32[uig_instnorm_workspace_floats(B,HW,C)].                                                    */

@@ -39,6 +39,38 @@ extern "C" int uig_pack_weight(const float* w, void* wp, int D0, int D1, int kH,
     return 0;
 }
 
+// All layers of all networks in ONE launch (140 separate pack launches cost 0.67 ms per step).  items[] lives in device
+// memory: per layer and operand one record with absolute pointers; work_end is the inclusive prefix sum of output elements.
+struct PackItem {
+    const float* w; void* dst;
+    int D0, D1, taps, row_dim, rows_p, cols_p;
+    long work_end;
+};
+static_assert(sizeof(PackItem) == 48, "PackItem layout is mirrored by the Python host code");
+template <typename T>
+__global__ void pack_weights_multi_kernel(const PackItem* __restrict__ items, int nitems, long total) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = nitems - 1;                 // first item whose work_end > i
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (items[mid].work_end > i) hi = mid; else lo = mid + 1; }
+        const PackItem it = items[lo];
+        const long j = i - (lo ? items[lo - 1].work_end : 0);
+        const int col = (int)(j % it.cols_p); const long r = j / it.cols_p; const int tap = (int)(r % it.taps); const int row = (int)(r / it.taps);
+        const int d0 = it.row_dim == 0 ? row : col, d1 = it.row_dim == 0 ? col : row;
+        float v = 0.f;
+        if (d0 < it.D0 && d1 < it.D1) v = it.w[((long)d0 * it.D1 + d1) * it.taps + tap];
+        ElemTraits<T>::st(static_cast<T*>(it.dst) + j, v);
+    }
+}
+extern "C" int uig_pack_weights_multi(const void* items_dev, int nitems, int64_t total_work, int dtype, void* stream) {
+    UIG_CHECK_ARG(items_dev && nitems > 0 && total_work > 0, "uig_pack_weights_multi: bad args");
+    const int g = grid_for(total_work, 4);
+    if (dtype == UIG_BF16) hipLaunchKernelGGL((pack_weights_multi_kernel<bf16_t>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const PackItem*)items_dev, nitems, (long)total_work);
+    else if (dtype == UIG_F32) hipLaunchKernelGGL((pack_weights_multi_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const PackItem*)items_dev, nitems, (long)total_work);
+    else return uig_set_error(-1, "uig_pack_weights_multi: bad dtype %d", dtype);
+    UIG_LAUNCH_CHECK("uig_pack_weights_multi");
+    return 0;
+}
+
 // ------------------------------------------------------------------ reflection-pad backward (fold)
 template <typename T>
 __global__ void reflect_fold_kernel(const T* __restrict__ dyp, T* __restrict__ dx, int B, int H, int W, int C, int P) {

@@ -67,8 +67,11 @@ class CycleGAN:
         self.repack()
 
     def repack(self):
-        for n in self.nets():
-            n.repack()
+        """refresh every layer's kernel-side weight operands from the fp32 master copy: one launch for all four networks"""
+        mp = getattr(self, "_packer", None)
+        if mp is None or not mp.valid():
+            mp = self._packer = ops.MultiPacker([l for n in self.nets() for l in n.conv_layers()])
+        mp.run()
 
     def broadcast_params(self, src=0):
         self.xchg.broadcast(self.grp_G.flat, src)

@@ -156,6 +156,46 @@ def pack_weights(spec: ConvSpec, weight: torch.Tensor, dtype: torch.dtype, wp_fw
         L.check(lib.uig_pack_weight(_p(weight), _p(wp_dgrad), D0, D1, k, k, L.PACK_ROW_DIM0, 0, spec.cin, spec.cout_p, dt, s), "uig_pack_weight")
 
 
+class MultiPacker:
+    """Packs every ConvLayer of a set of networks in ONE kernel launch (uig_pack_weights_multi).  The descriptor table holds
+    absolute device pointers, so it must be rebuilt if parameters or packed buffers are re-allocated (`valid()` checks)."""
+
+    def __init__(self, layers):
+        import numpy as np
+        self.layers = list(layers)
+        dt = np.dtype([("w", "<u8"), ("dst", "<u8"), ("D0", "<i4"), ("D1", "<i4"), ("taps", "<i4"), ("row_dim", "<i4"),
+                       ("rows_p", "<i4"), ("cols_p", "<i4"), ("work_end", "<i8")])
+        assert dt.itemsize == 48
+        recs, end = [], 0
+        for l in self.layers:
+            sp, w = l.spec, l.weight
+            t = sp.k * sp.k
+            D0, D1 = w.shape[0], w.shape[1]
+            if sp.kind == "conv":      # fwd rows = dim0 (Cout), dgrad rows = dim1 (Cin)
+                ops_ = ((l.wp_fwd, L.PACK_ROW_DIM0, sp.cout, sp.cin_p), (l.wp_dgrad, L.PACK_ROW_DIM1, sp.cin, sp.cout_p))
+            else:
+                ops_ = ((l.wp_fwd, L.PACK_ROW_DIM1, sp.cout, sp.cin_p), (l.wp_dgrad, L.PACK_ROW_DIM0, sp.cin, sp.cout_p))
+            for dst, rd, rows, cols in ops_:
+                assert dst.numel() == rows * t * cols
+                end += rows * t * cols
+                recs.append((w.data_ptr(), dst.data_ptr(), D0, D1, t, rd, rows, cols, end))
+        self.total = end
+        self.ptrs = [(l.weight.data_ptr(), l.wp_fwd.data_ptr(), l.wp_dgrad.data_ptr()) for l in self.layers]
+        arr = np.array(recs, dtype=dt)
+        self.dtype = self.layers[0].compute_dtype
+        self.items = torch.from_numpy(arr.view(np.uint8).copy()).to(self.layers[0].weight.device)
+        self.n = len(recs)
+
+    def valid(self):
+        return all(p == (l.weight.data_ptr(), l.wp_fwd.data_ptr(), l.wp_dgrad.data_ptr()) for p, l in zip(self.ptrs, self.layers))
+
+    def run(self):
+        dt = L.BF16 if self.dtype == torch.bfloat16 else L.F32
+        L.check(L.lib().uig_pack_weights_multi(_p(self.items), self.n, self.total, dt, _stream()), "uig_pack_weights_multi")
+        for l in self.layers:
+            l._packed_version = l.weight._version
+
+
 def packed_shapes(spec: ConvSpec):
     t = spec.k * spec.k
     return (spec.cout, t, spec.cin_p), (spec.cin, t, spec.cout_p)
