@@ -91,6 +91,10 @@ int uig_wgrad_partial(const void* P, const void* Q, float* workspace, int B, int
 /* dW[d0][d1][tap] (+)= sum_s part[s][d0][tap][d1]  for d0 < D0, d1 < D1 (the real, unpadded channel counts) */
 int uig_wgrad_reduce(const float* workspace, float* dW, int Np, int Cq, int taps, int splits,
                      int D0, int D1, int accumulate, void* stream);
+/* uig_wgrad_reduce + the layer's bias gradient from the InstanceNorm backward's column-sum partials, in one launch */
+int uig_wgrad_reduce_bias(const float* workspace, float* dW, int Np, int Cq, int taps, int splits,
+                          int D0, int D1, int accumulate, const float* colsum_partial, int nslab_total, int C,
+                          int Nreal, float* db, int accumulate_db, void* stream);
 /* db[n] (+)= sum over all B*H*W pixels of dy[m][n], n < Nreal (aten::convolution_backward bias grad).
  * workspace: fp32[uig_colsum_workspace_floats(C)] */
 size_t uig_colsum_workspace_floats(int C);

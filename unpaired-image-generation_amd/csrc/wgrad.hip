@@ -231,17 +231,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const T* __restrict__ P, 
     }
 }
 
+// Optional rider on the reduce launch: the bias gradient from the InstanceNorm backward's column-sum partials
+// (partial[slab][C][2], see instnorm.hip) - saves one tiny launch per layer on the backward's side stream.
+struct BiasRider { const float* cpart; float* db; int nslab, C, nreal, accumulate, main_blocks; };
+__device__ __forceinline__ void bias_rider_block(const BiasRider& br, int blk) {
+    const int sl = threadIdx.x & 15, c = blk * 16 + (threadIdx.x >> 4);
+    double a = 0.0;
+    if (c < br.C)
+        for (int s = sl; s < br.nslab; s += 16) a += (double)br.cpart[((long)s * br.C + c) * 2];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 16);
+    if (sl == 0 && c < br.nreal) br.db[c] = br.accumulate ? br.db[c] + (float)a : (float)a;
+}
+
 // dW[d0][d1][tap] (+)= sum_s part[s][d0][tap][d1]
 // One thread per (d0, d1): for every tap the reads of consecutive threads are consecutive d1 (coalesced slabs), and each
 // thread writes its `taps` consecutive output floats, so a wave writes one contiguous 64*taps*4-byte run (the earlier
 // one-thread-per-element form wrote with a stride of `taps` floats and ran at 1.6 TB/s).
 template <int TAPS>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int Np, int Cq,
-                                                            int taps_rt, int splits, int D0, int D1, int accumulate) {
+                                                            int taps_rt, int splits, int D0, int D1, int accumulate, const BiasRider br) {
+    if ((int)blockIdx.x >= br.main_blocks) { bias_rider_block(br, blockIdx.x - br.main_blocks); return; }
     const int taps = TAPS > 0 ? TAPS : taps_rt;
     const long slab = (long)Np * taps * Cq;
     const int total = D0 * D1;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += br.main_blocks * blockDim.x) {
         const int d1 = i % D1, d0 = i / D1;
         const float* src = part + (long)d0 * taps * Cq + d1;
         float* dst = dW + (long)i * taps;
@@ -266,11 +280,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 // few (d0, d1) pairs (3-channel stem / head, 1-channel discriminator head): one thread per output ELEMENT instead
-__global__ void wgrad_reduce_elem_kernel(const float* __restrict__ part, float* __restrict__ dW, int Np, int Cq, int taps,
-                                         int splits, int D0, int D1, int accumulate) {
+__global__ __launch_bounds__(256) void wgrad_reduce_elem_kernel(const float* __restrict__ part, float* __restrict__ dW, int Np, int Cq, int taps,
+                                                                 int splits, int D0, int D1, int accumulate, const BiasRider br) {
+    if ((int)blockIdx.x >= br.main_blocks) { bias_rider_block(br, blockIdx.x - br.main_blocks); return; }
     const long total = (long)D0 * D1 * taps;
     const long slab = (long)Np * taps * Cq;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)br.main_blocks * blockDim.x) {
         const int d1 = (int)(i % D1); const long r = i / D1; const int tap = (int)(r % taps); const int d0 = (int)(r / taps);
         const long src = ((long)d0 * taps + tap) * Cq + d1;
         float s = 0.f;
@@ -334,19 +349,38 @@ extern "C" int uig_wgrad_partial(const void* P, const void* Q, float* workspace,
     return fast ? launch_wgrad<float, 128, true>(P, Q, workspace, d, splits, s) : launch_wgrad<float, 128, false>(P, Q, workspace, d, splits, s);
 }
 
-extern "C" int uig_wgrad_reduce(const float* workspace, float* dW, int Np, int Cq, int taps, int splits,
-                                int D0, int D1, int accumulate, void* stream) {
+static int wgrad_reduce_impl(const float* workspace, float* dW, int Np, int Cq, int taps, int splits, int D0, int D1, int accumulate,
+                             BiasRider br, void* stream) {
     UIG_CHECK_ARG(workspace && dW, "uig_wgrad_reduce: null pointer");
     UIG_CHECK_ARG(D0 <= Np && D1 <= Cq && D0 > 0 && D1 > 0 && taps > 0 && splits > 0, "uig_wgrad_reduce: bad dims");
     const long total = (long)D0 * D1;
-    const int blocks = (int)std::max<long>(1, std::min<long>((total + 255) / 256, 4096));
     hipStream_t s = (hipStream_t)stream;
+    const int extra = br.cpart ? (br.C + 15) / 16 : 0;
     if (total < 8192) {
         const long tot_e = total * taps;
-        hipLaunchKernelGGL(wgrad_reduce_elem_kernel, dim3((int)std::min<long>((tot_e + 255) / 256, 4096)), dim3(256), 0, s, workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate);
-    } else if (taps == 9) hipLaunchKernelGGL(wgrad_reduce_kernel<9>, dim3(blocks), dim3(256), 0, s, workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate);
-    else if (taps == 16) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(blocks), dim3(256), 0, s, workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate);
-    else hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3(blocks), dim3(256), 0, s, workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate);
+        br.main_blocks = (int)std::max<long>(1, std::min<long>((tot_e + 255) / 256, 4096));
+        hipLaunchKernelGGL(wgrad_reduce_elem_kernel, dim3(br.main_blocks + extra), dim3(256), 0, s, workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate, br);
+    } else {
+        br.main_blocks = (int)std::max<long>(1, std::min<long>((total + 255) / 256, 4096));
+        const dim3 g(br.main_blocks + extra);
+        if (taps == 9) hipLaunchKernelGGL(wgrad_reduce_kernel<9>, g, dim3(256), 0, s, workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate, br);
+        else if (taps == 16) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, g, dim3(256), 0, s, workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate, br);
+        else hipLaunchKernelGGL(wgrad_reduce_kernel<0>, g, dim3(256), 0, s, workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate, br);
+    }
     UIG_LAUNCH_CHECK("uig_wgrad_reduce");
     return 0;
+}
+
+extern "C" int uig_wgrad_reduce(const float* workspace, float* dW, int Np, int Cq, int taps, int splits,
+                                int D0, int D1, int accumulate, void* stream) {
+    return wgrad_reduce_impl(workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate, BiasRider{nullptr, nullptr, 0, 0, 0, 0, 0}, stream);
+}
+
+// the same launch also finishes the layer's bias gradient from column-sum partials (uig_instnorm_act_bwd_colsum)
+extern "C" int uig_wgrad_reduce_bias(const float* workspace, float* dW, int Np, int Cq, int taps, int splits,
+                                     int D0, int D1, int accumulate, const float* colsum_partial, int nslab_total, int C,
+                                     int Nreal, float* db, int accumulate_db, void* stream) {
+    UIG_CHECK_ARG(colsum_partial && db && nslab_total > 0 && Nreal > 0 && Nreal <= C, "uig_wgrad_reduce_bias: bad bias args");
+    return wgrad_reduce_impl(workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate,
+                             BiasRider{colsum_partial, db, nslab_total, C, Nreal, accumulate_db, 0}, stream);
 }

@@ -33,6 +33,7 @@ SIGNATURES = {
     "uig_wgrad_workspace_bytes": (_sz, [_i] * 5),
     "uig_wgrad_partial": (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp]),
     "uig_wgrad_reduce": (_i, [_vp, _vp] + [_i] * 7 + [_vp]),
+    "uig_wgrad_reduce_bias": (_i, [_vp, _vp] + [_i] * 7 + [_vp, _i, _i, _i, _vp, _i, _vp]),
     "uig_colsum_workspace_floats": (_sz, [_i]),
     "uig_bias_grad": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "uig_pack_weight": (_i, [_vp, _vp] + [_i] * 9 + [_vp]),

@@ -302,7 +302,8 @@ def _wgrad_splits(tiles: int, M: int) -> int:
     return max(1, min(512 // max(tiles, 1), M // 128))
 
 
-def conv_wgrad(spec: ConvSpec, x: torch.Tensor, dy: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = False) -> torch.Tensor:
+def conv_wgrad(spec: ConvSpec, x: torch.Tensor, dy: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = False,
+               bias_rider=None) -> torch.Tensor:
     """aten::convolution_backward, weight gradient (fp32, torch layout).  With `out` the split-K reduce writes (or, with
     accumulate=True, adds) straight into that tensor, e.g. the layer's slice of the flat gradient buffer."""
     lib, s = L.lib(), _stream()
@@ -327,7 +328,13 @@ def conv_wgrad(spec: ConvSpec, x: torch.Tensor, dy: torch.Tensor, out: torch.Ten
         out, accumulate = torch.empty(spec.weight_shape(), device=x.device, dtype=torch.float32), False
     elif not (out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == tuple(spec.weight_shape())):
         raise ValueError("conv_wgrad: `out` must be a contiguous fp32 tensor of the weight's shape")
-    L.check(lib.uig_wgrad_reduce(_p(ws), _p(out), Np, Cq, k * k, splits, D0, D1, 1 if accumulate else 0, s), "uig_wgrad_reduce")
+    if bias_rider is not None:      # (colsum tuple, first image, images, db, accumulate_db): bias gradient rides on the reduce launch
+        (cpart, slabs_per_img, C), img0, nimg, db, acc_b = bias_rider
+        sub = cpart[img0 * slabs_per_img * C * 2:]
+        L.check(lib.uig_wgrad_reduce_bias(_p(ws), _p(out), Np, Cq, k * k, splits, D0, D1, 1 if accumulate else 0, _p(sub),
+                                          nimg * slabs_per_img, C, spec.cout, _p(db), 1 if acc_b else 0, s), "uig_wgrad_reduce_bias")
+    else:
+        L.check(lib.uig_wgrad_reduce(_p(ws), _p(out), Np, Cq, k * k, splits, D0, D1, 1 if accumulate else 0, s), "uig_wgrad_reduce")
     return out
 
 
@@ -355,12 +362,17 @@ def _param_grads(layer, spec, x, dy, need_w, need_b, colsum=None, img0=0):
     earlier backward) the reduce kernels ADD into it in place and autograd gets None (= nothing more to accumulate):
     gradient-accumulation fusion, no temporary dW and no extra add kernel.  Otherwise they are returned the usual way."""
     dW = db = None
+    b = layer.bias
+    rider = None
+    if need_w and need_b and colsum is not None and colsum[2] == dy.shape[3] and layer.fuse_grad_accum and b.grad is not None \
+            and b.grad.is_contiguous():
+        rider, need_b = (colsum, img0, dy.shape[0], b.grad, True), False       # bias gradient finished by the reduce launch
     if need_w:
         w = layer.weight
         if layer.fuse_grad_accum and w.grad is not None and w.grad.is_contiguous():
-            conv_wgrad(spec, x, dy, out=w.grad, accumulate=True)
+            conv_wgrad(spec, x, dy, out=w.grad, accumulate=True, bias_rider=rider)
         else:
-            dW = conv_wgrad(spec, x, dy)
+            dW = conv_wgrad(spec, x, dy, bias_rider=rider)
     if need_b:
         b = layer.bias
         fused = layer.fuse_grad_accum and b.grad is not None and b.grad.is_contiguous()
