@@ -310,8 +310,8 @@ void igemm_kernel(const T* __restrict__ x, const T* __restrict__ wp_, const floa
 #define UIG_INST(T, BM, BN, WMV, WNV, NS) \
     template __global__ void igemm_kernel<T, BM, BN, WMV, WNV, NS, true>(const T*, const T*, const float*, T*, const GatherDesc); \
     template __global__ void igemm_kernel<T, BM, BN, WMV, WNV, NS, false>(const T*, const T*, const float*, T*, const GatherDesc);
-UIG_INST(bf16_t, 256, 16, 4, 1, 2) UIG_INST(bf16_t, 128, 64, 2, 2, 2) UIG_INST(bf16_t, 128, 128, 2, 2, 2) UIG_INST(bf16_t, 128, 256, 2, 4, 3)
-UIG_INST(float, 256, 16, 4, 1, 2) UIG_INST(float, 128, 64, 2, 2, 2) UIG_INST(float, 128, 128, 2, 2, 2) UIG_INST(float, 128, 256, 2, 4, 3)
+UIG_INST(bf16_t, 256, 16, 4, 1, 2) UIG_INST(bf16_t, 128, 64, 2, 2, 2) UIG_INST(bf16_t, 128, 128, 2, 2, 2) UIG_INST(bf16_t, 128, 256, 2, 4, 3) UIG_INST(bf16_t, 128, 128, 2, 2, 3)
+UIG_INST(float, 256, 16, 4, 1, 2) UIG_INST(float, 128, 64, 2, 2, 2) UIG_INST(float, 128, 128, 2, 2, 2) UIG_INST(float, 128, 256, 2, 4, 3) UIG_INST(float, 128, 128, 2, 2, 3)
 #undef UIG_INST
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -353,6 +353,10 @@ static int dispatch_igemm(const void* x, const void* wp, const float* bias, void
     if (wide)      // full-width tile: the im2col tile is staged once per pixel tile, 8 waves, 3-stage DMA ring
         return small ? launch_igemm<T, 128, 256, 2, 4, 3, true>(x, wp, bias, y, d, s)
                      : launch_igemm<T, 128, 256, 2, 4, 3, false>(x, wp, bias, y, d, s);
+    // 3-stage ring with counted vmcnt for the 128x128 tile (two tiles in flight, 96 KB of LDS): measured no better than the
+    // 2-stage form even on small, latency-bound grids (border GEMM 17.2 vs 16.1 us, D4 conv 54.8 vs 52.5 us): hook only.
+    if (!small && g_force_tile == 3)
+        return launch_igemm<T, 128, 128, 2, 2, 3, false>(x, wp, bias, y, d, s);
     return small ? launch_igemm<T, 128, 128, 2, 2, 2, true>(x, wp, bias, y, d, s)
                  : launch_igemm<T, 128, 128, 2, 2, 2, false>(x, wp, bias, y, d, s);
 }
