@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void in_apply_bwd_kernel(const T* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-static int stats_slabs(long HW, int CC) { return (int)std::max<long>(1, std::min<long>(128, HW * CC / (256 * 16))); }
+static int stats_slabs(long HW, int CC) { return (int)std::max<long>(1, std::min<long>(128, HW * CC / (256 * 4))); }
 static int apply_slabs(long HW, int CC) { return (int)std::max<long>(1, std::min<long>(2048, HW * CC / (256 * 4))); }
 
 static int check_in_args(const char* fn, int B, long HW, int C, int dtype, int* CC) {
