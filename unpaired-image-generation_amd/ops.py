@@ -298,8 +298,11 @@ def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, 
     return dx
 
 
+_WGRAD_BLOCKS = int(os.environ.get("UIG_WGRAD_BLOCKS", "512"))   # target grid of the split-K weight-gradient kernel (2 blocks per CU)
+
+
 def _wgrad_splits(tiles: int, M: int) -> int:
-    return max(1, min(512 // max(tiles, 1), M // 128))
+    return max(1, min(_WGRAD_BLOCKS // max(tiles, 1), M // 128))
 
 
 def conv_wgrad(spec: ConvSpec, x: torch.Tensor, dy: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = False,
