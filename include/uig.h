@@ -85,6 +85,10 @@ int uig_conv_strip_applicable(int B, int H, int W, int Cin, int Nrows, int Ho, i
  * P: dense operand (B,Mh,Mw,Np) (dy for Conv2d, x for ConvTranspose2d); Q: gathered operand (B,Hq,Wq,Cq) read at
  * (i*stride + kh - pad, j*stride + kw - pad) with zero/reflect padding.  workspace: fp32[splits*Np*kH*kW*Cq].   */
 size_t uig_wgrad_workspace_bytes(int Np, int Cq, int kH, int kW, int splits);
+/* rows of the dense operand covered by one block of uig_wgrad_partial for this shape (16 / 128 / 256): the number of
+ * output tiles, from which the caller chooses `splits`, is ceil(Np / rows) * ceil(kH*kW*Cq / 128). */
+int uig_wgrad_tile_rows(int Np, int Mw, int dtype);
+void uig_debug_set_wgrad_wide(int on);   /* tuning hook: 0 = never use the 256-row tile */
 int uig_wgrad_partial(const void* P, const void* Q, float* workspace, int B, int Mh, int Mw, int Np,
                       int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int pad_mode,
                       int splits, int dtype, void* stream);

@@ -27,19 +27,22 @@ template <> struct WgTraits<float> { static constexpr int PAD = 64; };
 
 // FASTROW: Mw % BKP == 0, so the BKP pixels of a K-step lie in ONE image row: the (image, row) part of the gather address
 // is computed once per K-step from block-uniform running coordinates and only the column part per staged row.
+// BN = 256 runs 8 waves (512 threads): the gathered Q tile is staged once for all 256 rows of the dense operand instead of
+// once per 128-row tile (48 KB instead of 64 KB of staging per 2.1 MMAC).
 template <typename T, int BN, bool FASTROW>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const T* __restrict__ P, const T* __restrict__ Q,
+__global__ __launch_bounds__((BN >= 256 ? 512 : 256), 2) void wgrad_kernel(const T* __restrict__ P, const T* __restrict__ Q,
                                                         float* __restrict__ part, const WgradDesc d) {
     constexpr int E = ElemTraits<T>::E;
     constexpr int BC = 128;
     constexpr int BKP = (sizeof(T) == 2) ? 64 : 32;   // pixels per K-step: bf16 64 (two MFMA k-groups per barrier), f32 32
-    constexpr int WAVES_N = (BN >= 128) ? 2 : 1, WAVES_C = 4 / WAVES_N;
+    constexpr int NTHR = (BN >= 256) ? 512 : 256, NWAVE = NTHR / 64;
+    constexpr int WAVES_N = (BN >= 256) ? 4 : (BN >= 128) ? 2 : 1, WAVES_C = NWAVE / WAVES_N;
     constexpr int WN = BN / WAVES_N, WC = BC / WAVES_C, NT = WN / 16, CT = WC / 16;
     constexpr int PROW = BN * (int)sizeof(T) + WgTraits<T>::PAD;      // LDS row strides (bytes)
     constexpr int QROW = BC * (int)sizeof(T) + WgTraits<T>::PAD;
     constexpr int STAGE = BKP * (PROW + QROW);
     constexpr int PCH = BN / E, QCH = BC / E;                          // 16-byte chunks per row
-    constexpr int PI = (BKP * PCH + 255) / 256, QI = (BKP * QCH + 255) / 256;
+    constexpr int PI = (BKP * PCH + NTHR - 1) / NTHR, QI = (BKP * QCH + NTHR - 1) / NTHR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const T* __restrict__ P, 
     int q_c[QI], q_dh[QI], q_dw[QI], q_row[QI]; bool q_ok[QI];
 #pragma unroll
     for (int i = 0; i < QI; ++i) {
-        const int id = tid + 256 * i;
+        const int id = tid + NTHR * i;
         q_row[i] = id / QCH;
         const int col = col_base + (id % QCH) * E;
         q_ok[i] = (id < BKP * QCH) && (col < d.ncols);
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const T* __restrict__ P, 
     int p_n[PI], p_row[PI]; bool p_ok[PI];
 #pragma unroll
     for (int i = 0; i < PI; ++i) {
-        const int id = tid + 256 * i;
+        const int id = tid + NTHR * i;
         p_row[i] = id / PCH;
         p_n[i] = n_base + (id % PCH) * E;
         p_ok[i] = (id < BKP * PCH) && (p_n[i] < d.Np);
@@ -138,12 +141,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const T* __restrict__ P, 
         unsigned char* sq = sp + BKP * PROW;
 #pragma unroll
         for (int i = 0; i < QI; ++i) {
-            const int id = tid + 256 * i;
+            const int id = tid + NTHR * i;
             if (id < BKP * QCH) *reinterpret_cast<u32x4_t*>(sq + q_row[i] * QROW + (id % QCH) * 16) = rq[i];
         }
 #pragma unroll
         for (int i = 0; i < PI; ++i) {
-            const int id = tid + 256 * i;
+            const int id = tid + NTHR * i;
             if (id < BKP * PCH) *reinterpret_cast<u32x4_t*>(sp + p_row[i] * PROW + (id % PCH) * 16) = rp[i];
         }
     };
@@ -311,9 +314,18 @@ static int launch_wgrad(const void* P, const void* Q, float* ws, const WgradDesc
         attr_done = true;
     }
     const int ntn = (d.Np + BN - 1) / BN, ntc = (d.ncols + 127) / 128;
-    hipLaunchKernelGGL(kern, dim3(ntn * ntc, splits), dim3(256), smem, s, (const T*)P, (const T*)Q, ws, d);
+    hipLaunchKernelGGL(kern, dim3(ntn * ntc, splits), dim3(BN >= 256 ? 512 : 256), smem, s, (const T*)P, (const T*)Q, ws, d);
     UIG_LAUNCH_CHECK("uig_wgrad_partial");
     return 0;
+}
+
+static int g_wgrad_bn256 = 0;   // measured slower (73.9 vs 68 us at batch 8: one 8-wave block per CU runs in lockstep, two 4-wave blocks cover each other)
+extern "C" void uig_debug_set_wgrad_wide(int on) { g_wgrad_bn256 = on; }
+// rows of the dense operand one block covers for this launch (16, 128 or 256): the caller sizes `splits` from it
+extern "C" int uig_wgrad_tile_rows(int Np, int Mw, int dtype) {
+    const int bkp = dtype == UIG_BF16 ? 64 : 32;
+    if (g_wgrad_bn256 && Np % 256 == 0 && (Mw % bkp) == 0) return 256;
+    return Np <= 16 ? 16 : 128;
 }
 
 extern "C" int uig_wgrad_partial(const void* P, const void* Q, float* workspace, int B, int Mh, int Mw, int Np,
@@ -341,6 +353,10 @@ extern "C" int uig_wgrad_partial(const void* P, const void* Q, float* workspace,
     hipStream_t s = (hipStream_t)stream;
     const int bkp = dtype == UIG_BF16 ? 64 : 32;
     const bool fast = (Mw % bkp) == 0;          // a K-step never leaves its image row (Mper is a multiple of bkp)
+    if (g_wgrad_bn256 && Np % 256 == 0 && fast) {       // wide dense tile (the caller halves `splits`: uig_wgrad_tile_rows)
+        return dtype == UIG_BF16 ? launch_wgrad<bf16_t, 256, true>(P, Q, workspace, d, splits, s)
+                                 : launch_wgrad<float, 256, true>(P, Q, workspace, d, splits, s);
+    }
     if (dtype == UIG_BF16) {
         if (Np <= 16) return fast ? launch_wgrad<bf16_t, 16, true>(P, Q, workspace, d, splits, s) : launch_wgrad<bf16_t, 16, false>(P, Q, workspace, d, splits, s);
         return fast ? launch_wgrad<bf16_t, 128, true>(P, Q, workspace, d, splits, s) : launch_wgrad<bf16_t, 128, false>(P, Q, workspace, d, splits, s);

@@ -31,6 +31,8 @@ SIGNATURES = {
     "uig_reflect3x3_dgrad_border": (_i, [_vp, _vp, _vp, _i, _vp] + [_i] * 7 + [_vp]),
     "uig_conv_strip_applicable": (_i, [_i] * 10),
     "uig_wgrad_workspace_bytes": (_sz, [_i] * 5),
+    "uig_wgrad_tile_rows": (_i, [_i, _i, _i]),
+    "uig_debug_set_wgrad_wide": (None, [_i]),
     "uig_wgrad_partial": (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp]),
     "uig_wgrad_reduce": (_i, [_vp, _vp] + [_i] * 7 + [_vp]),
     "uig_wgrad_reduce_bias": (_i, [_vp, _vp] + [_i] * 7 + [_vp, _i, _i, _i, _vp, _i, _vp]),

@@ -321,9 +321,9 @@ def conv_wgrad(spec: ConvSpec, x: torch.Tensor, dy: torch.Tensor, out: torch.Ten
         Pt, Qt, Mh, Mw, Np, Hq, Wq, Cq = x, dy, H, W, spec.cin_p, Ho, Wo, spec.cout_p
         pm = L.PAD_ZERO
         D0, D1 = spec.cin, spec.cout
-    bn = 16 if Np <= 16 else 128
+    bn = int(lib.uig_wgrad_tile_rows(Np, Mw, _dt(x)))
     tiles = ((Np + bn - 1) // bn) * ((k * k * Cq + 127) // 128)
-    splits = _wgrad_splits(tiles, B * Mh * Mw)
+    splits = _wgrad_splits(tiles, B * Mh * Mw) if bn < 256 else max(1, min(256 // tiles, (B * Mh * Mw) // 128))   # 256-row tile: 1 block (8 waves) per CU
     ws = torch.empty((splits * Np * k * k * Cq,), device=x.device, dtype=torch.float32)
     L.check(lib.uig_wgrad_partial(_p(Pt), _p(Qt), _p(ws), B, Mh, Mw, Np, Hq, Wq, Cq, k, k, spec.stride, spec.pad, pm,
                                   splits, _dt(x), s), "uig_wgrad_partial")
