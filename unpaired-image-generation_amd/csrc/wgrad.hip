@@ -282,19 +282,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-// few (d0, d1) pairs (3-channel stem / head, 1-channel discriminator head): one thread per output ELEMENT instead
+// few (d0, d1) pairs (3-channel stem / head, 1-channel discriminator head): 16 output ELEMENTS per block, 16 split lanes per
+// element (these layers run with up to 512 splits; one thread per element walked them serially: 100+ us)
 __global__ __launch_bounds__(256) void wgrad_reduce_elem_kernel(const float* __restrict__ part, float* __restrict__ dW, int Np, int Cq, int taps,
                                                                  int splits, int D0, int D1, int accumulate, const BiasRider br) {
     if ((int)blockIdx.x >= br.main_blocks) { bias_rider_block(br, blockIdx.x - br.main_blocks); return; }
     const long total = (long)D0 * D1 * taps;
     const long slab = (long)Np * taps * Cq;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)br.main_blocks * blockDim.x) {
-        const int d1 = (int)(i % D1); const long r = i / D1; const int tap = (int)(r % taps); const int d0 = (int)(r / taps);
+    const int sl = threadIdx.x & 15;
+    for (long i = (long)blockIdx.x * 16 + (threadIdx.x >> 4); i < total + 15; i += (long)br.main_blocks * 16) {   // uniform trip count per 16-lane group
+        const bool ok = i < total;
+        const long ii = ok ? i : 0;
+        const int d1 = (int)(ii % D1); const long r = ii / D1; const int tap = (int)(r % taps); const int d0 = (int)(r / taps);
         const long src = ((long)d0 * taps + tap) * Cq + d1;
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += part[k * slab + src];
-        const long dst = ((long)d0 * D1 + d1) * taps + tap;
-        dW[dst] = accumulate ? dW[dst] + s : s;
+        float sacc = 0.f;
+        if (ok) for (int k = sl; k < splits; k += 16) sacc += part[k * slab + src];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 16);
+        if (ok && sl == 0) {
+            const long dst = ((long)d0 * D1 + d1) * taps + tap;
+            dW[dst] = accumulate ? dW[dst] + sacc : sacc;
+        }
     }
 }
 
@@ -374,7 +382,7 @@ static int wgrad_reduce_impl(const float* workspace, float* dW, int Np, int Cq, 
     const int extra = br.cpart ? (br.C + 15) / 16 : 0;
     if (total < 8192) {
         const long tot_e = total * taps;
-        br.main_blocks = (int)std::max<long>(1, std::min<long>((tot_e + 255) / 256, 4096));
+        br.main_blocks = (int)std::max<long>(1, std::min<long>((tot_e + 15) / 16, 4096));
         hipLaunchKernelGGL(wgrad_reduce_elem_kernel, dim3(br.main_blocks + extra), dim3(256), 0, s, workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate, br);
     } else {
         br.main_blocks = (int)std::max<long>(1, std::min<long>((total + 255) / 256, 4096));
