@@ -60,7 +60,16 @@ def _capture(model, real_A, real_B):
 def graph_train_step(model, real_A, real_B):
     st = model._graphs
     if st is None or st.real_A.shape != real_A.shape or st.real_B.shape != real_B.shape:
-        st = model._graphs = _capture(model, real_A, real_B)
+        try:
+            st = model._graphs = _capture(model, real_A, real_B)
+        except RuntimeError as e:
+            # Capture is an optimisation, not a requirement: if the runtime refuses it (e.g. another thread touched the
+            # device mid-capture), say so loudly once and run the identical kernel sequence eagerly from now on.
+            import sys
+            print(f"[uig] HIP-graph capture failed ({e}); continuing in eager mode", file=sys.stderr, flush=True)
+            torch.cuda.synchronize(model.device)
+            model._graphs, model.use_graph = None, False
+            return model._step_eager(model.to_phys(real_A), model.to_phys(real_B))
     st.real_A.copy_(real_A, non_blocking=True)
     st.real_B.copy_(real_B, non_blocking=True)
     st.g1.replay()
