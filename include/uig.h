@@ -40,6 +40,8 @@ int uig_device_ok(void); /* 1 if a gfx950 device is visible to the HIP runtime *
 void uig_debug_set_tile(int bn);
 /* tuning / test hook: 1 (default) = stride-1 3x3 convs use the LDS-resident-strip kernel, 0 = always the generic gather */
 void uig_debug_set_strip(int on);
+/* tuning / test hook: 1 (default) = 7x7 stride-1 convs with <= 16 output channels use the row-strip kernel */
+void uig_debug_set_rowstrip(int on);
 /* diagnostic build hook: device buffer (u64[blocks*8*4]) that receives in-kernel cycle stamps; NULL = off (default) */
 void uig_debug_set_strip_stamps(void* dev_buf);
 

@@ -366,6 +366,11 @@ int uig_try_conv_strip(const void* x, const void* wp, const float* bias, const v
                        int k, int pad_mode, const int* taps, int ntaps, int dh_min, int dh_max, int Ho, int Wo, int ldc, int Nstore,
                        int act, float slope, int dtype, long x_bytes, long w_bytes, hipStream_t s, int* rc_out);
 
+int uig_try_conv_rowstrip(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
+                          void* y, int B, int H, int W, int Cin, int Nrows, int k,
+                          int pad_mode, const int* taps, int ntaps, int Ho, int Wo, int ldc, int Nstore, int act, float slope,
+                          int dtype, long x_bytes, long w_bytes, hipStream_t s, int* rc_out);
+
 static int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
 static int conv_gather_impl(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
@@ -435,6 +440,12 @@ static int conv_gather_impl(const void* x, const void* wp, const float* bias, co
         d.in_partial = in_partial;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (d.nphase == 1 && stride == 1 && kH == kW && in_partial == nullptr && border_add == nullptr) {   // few output channels, many taps
+        int rc = 0;
+        if (uig_try_conv_rowstrip(x, wp, bias, wp2, bias2, group_images, y, B, H, W, Cin, Nrows, kH, pad_mode, d.tap, kH * kW, Ho, Wo,
+                                  ldc, Nstore, act, slope, dtype, (long)d.x_bytes, (long)d.w_bytes, s, &rc))
+            return rc;
+    }
     if (d.nphase == 1 && stride == 1 && kH == kW) {      // stride-1 k x k: LDS-resident input strip kernel (conv_strip.hip)
         int dmin = 127, dmax = -127, rc = 0;
         for (int t = 0; t < kH * kW; ++t) { const int dh = (d.tap[t] & 255) - 128; dmin = std::min(dmin, dh); dmax = std::max(dmax, dh); }

@@ -1,0 +1,213 @@
+// conv_rowstrip.hip — stride-1 k x k convolution with FEW output channels (N <= 16) and a large tap count: the 7x7
+// generator head (64 -> 3, forward) and the input gradient of the 7x7 stem (64 -> 3).
+//
+// The generic implicit-GEMM kernel stages a 256-pixel x 128-byte im2col tile for every one of the 49 taps while a wave
+// only has 8 MFMAs to run on it (N = 16): 49 x 34 KB of L2->LDS traffic per 256 output pixels (267 us per 8 images).
+// Here a block owns one 256-pixel segment of an output row and walks the kernel ROWS: per (channel chunk, kh) it loads
+// ONE input row segment (256 + k - 1 pixels x 128 B, reflection / zero padding resolved per pixel in the DMA source
+// address) plus the k weight tiles of that kernel row (k x 16 x 128 B) and generates the k taps of the row by shifted
+// fragment reads - 47 KB per 7 taps instead of 238 KB, one barrier per kernel row.  LDS-DMA staging, double buffered,
+// source-side XOR swizzle and MFMA 16x16 tiles exactly as in conv_igemm.hip / conv_strip.hip.
+#include "uig_common.h"
+#include <algorithm>
+
+struct RowStripDesc {
+    int B, H, W, Cin;
+    int Ho, Wo;
+    int k, R;                 // kernel size, halo (max |dw|)
+    int pad_mode;
+    int Nrows, ldw, ldc, Nstore;
+    int act; float slope;
+    unsigned x_bytes, w_bytes;
+    int tap[64];              // (dh + 128) | (dw + 128) << 8 | weight-tap-index << 16, kernel-row major
+    const void* wp2;          // paired launch: images >= group_images use wp2 / bias2
+    const float* bias2;
+    int group_images;
+};
+
+template <typename T> struct MmaR;
+template <> struct MmaR<bf16_t> {
+    static __device__ __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct MmaR<float> {
+    static __device__ __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b[e]), c, 0, 0, 0);
+    }
+};
+
+template <typename T, int KMAX>
+__global__ __launch_bounds__(256, 2)
+void conv_rowstrip_kernel(const T* __restrict__ x, const T* __restrict__ wp_, const float* __restrict__ bias_, T* __restrict__ y,
+                          const RowStripDesc d) {
+    constexpr int E = ElemTraits<T>::E;
+    constexpr int BK = 8 * E;
+    constexpr int BM = 256, MT = 4;                       // 4 waves x 64 pixels, one 16-channel MFMA column
+    constexpr int SROWS = (BM + KMAX - 1 + 7) / 8 * 8;    // strip rows (pixels), padded to whole 1-KiB DMA pieces
+    constexpr int SPIECES = SROWS / 8;
+    constexpr int SBUF = SROWS * 128;
+    constexpr int WBUF = KMAX * 16 * 128;                 // k weight tiles of 16 rows
+    constexpr int STAGE = SBUF + WBUF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [stage 0: strip | weights][stage 1: ...]
+    typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l8 = lane >> 3, ls = lane & 7, l16 = lane & 15, q = lane >> 4;
+
+    // ---- tile: (image, output row, 256-pixel segment)
+    const int segs = d.Wo / BM;
+    int t = blockIdx.x;
+    const int seg = t % segs; t /= segs;
+    const int ho = t % d.Ho, img = t / d.Ho;
+    const int w0 = seg * BM;
+    const int Cin = d.Cin, k = d.k, R = d.R;
+    const bool refl = d.pad_mode == UIG_PAD_REFLECT;
+    const bool g2 = d.wp2 != nullptr && img >= d.group_images;
+    const T* wp = g2 ? static_cast<const T*>(d.wp2) : wp_;
+    const float* bias = g2 ? d.bias2 : bias_;
+
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, d.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wp), 0, d.w_bytes, 0x00020000);
+
+    // group g = (channel chunk cc, kernel row kh): the strip is input row (ho + dh[kh]), pixels w0 - R .. w0 + BM - 1 + R
+    const int ncc = Cin / BK;
+    const int G = ncc * k;
+    auto issue_group = [&](int g, int stage) {
+        const int cc = g / k, kh = g - cc * k;
+        const int te0 = __builtin_amdgcn_readfirstlane(d.tap[kh * k]);
+        const int hi = ho + (te0 & 255) - 128;
+        const bool hin = (unsigned)hi < (unsigned)d.H;
+        const int hr = refl ? reflect_idx(hi, d.H) : hi;
+        const int rowbase = (img * d.H + hr) * d.W;
+        lds_ptr_t sdst = (lds_ptr_t)smem + stage * STAGE;
+        const int soff = __builtin_amdgcn_readfirstlane(cc * BK * (int)sizeof(T));
+        for (int j = wave; j < SPIECES; j += 4) {          // strip pieces: rows 8j .. 8j+7 of the strip
+            const int s = 8 * j + l8;
+            const int wi = w0 - R + s;
+            const bool win = (unsigned)wi < (unsigned)d.W;
+            const int wr = refl ? reflect_idx(wi, d.W) : wi;
+            const bool ok = (s < BM + 2 * R) & (refl | (hin & win));
+            const int csrc = ls ^ ((s >> 1) & 7);
+            const unsigned off = ok ? (unsigned)(((rowbase + wr) * Cin + csrc * E) * (int)sizeof(T)) : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(sdst + j * 1024), 16, (int)off, soff, 0, 0);
+        }
+        lds_ptr_t wdst = sdst + SBUF;
+        for (int j = wave; j < 2 * k; j += 4) {            // weight pieces: tap kw = j / 2, rows 8 (j % 2) .. + 7
+            const int kw = j >> 1, n = (j & 1) * 8 + l8;
+            const int te = d.tap[kh * k + kw];
+            const int csrc = ls ^ ((n >> 1) & 7);
+            const unsigned off = (n < d.Nrows) ? (unsigned)((n * d.ldw + (te >> 16) * Cin + csrc * E) * (int)sizeof(T)) : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(wdst + j * 1024), 16, (int)off, soff, 0, 0);
+        }
+    };
+
+    f32x4_t acc[MT];
+#pragma unroll
+    for (int b = 0; b < MT; ++b) acc[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    issue_group(0, 0);
+    const int pl = wave * 64 + l16;                        // this lane's pixel (tile-local) for m-tile 0
+    const int wsw = (l16 >> 1) & 7;
+    for (int g = 0; g < G; ++g) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (g + 1 < G) issue_group(g + 1, (g + 1) & 1);
+        const int kh = g % k;
+        const unsigned char* sx = smem + (g & 1) * STAGE;
+        const unsigned char* sw = sx + SBUF + l16 * 128;
+        for (int kw = 0; kw < k; ++kw) {
+            const int sft = ((d.tap[kh * k + kw] >> 8) & 255) - 128 + R;      // strip shift of this tap (block-uniform)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const u32x4_t wf = *reinterpret_cast<const u32x4_t*>(sw + kw * 2048 + (((q + 4 * h) ^ wsw) << 4));
+#pragma unroll
+                for (int b = 0; b < MT; ++b) {
+                    const int s = pl + b * 16 + sft;
+                    const u32x4_t xf = *reinterpret_cast<const u32x4_t*>(sx + s * 128 + (((q + 4 * h) ^ ((s >> 1) & 7)) << 4));
+                    MmaR<T>::run(wf, xf, acc[b]);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds channels 4q .. 4q+3 of pixel column l16 (N <= 16: direct stores)
+    const bool vec_ok = ((d.Nstore & 3) == 0) && ((d.ldc & 3) == 0);
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+        const int wo = w0 + pl + b * 16;
+        T* yp = y + ((long)(img * d.Ho + ho) * d.Wo + wo) * d.ldc;
+        const int n = 4 * q;
+        if (n >= d.Nstore) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float bv = (bias != nullptr && n + e < d.Nrows) ? bias[n + e] : 0.f;
+            v[e] = apply_act(acc[b][e] + bv, d.act, d.slope);
+        }
+        if (vec_ok) {
+            if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<f32x4_t*>(yp + n) = f32x4_t{v[0], v[1], v[2], v[3]};
+            } else {
+                u32x2_t pk;
+                pk[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                pk[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                *reinterpret_cast<u32x2_t*>(yp + n) = pk;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < d.Nstore) ElemTraits<T>::st(yp + n + e, v[e]);
+        }
+    }
+}
+
+template __global__ void conv_rowstrip_kernel<bf16_t, 7>(const bf16_t*, const bf16_t*, const float*, bf16_t*, const RowStripDesc);
+template __global__ void conv_rowstrip_kernel<float, 7>(const float*, const float*, const float*, float*, const RowStripDesc);
+
+static int g_rowstrip_mode = 1;
+extern "C" void uig_debug_set_rowstrip(int on) { g_rowstrip_mode = on; }
+
+template <typename T>
+static int launch_rowstrip(const void* x, const void* wp, const float* bias, void* y, const RowStripDesc& d, hipStream_t s) {
+    constexpr int SROWS = (256 + 7 - 1 + 7) / 8 * 8;
+    const size_t smem = 2 * (size_t)(SROWS * 128 + 7 * 16 * 128);
+    auto kern = conv_rowstrip_kernel<T, 7>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return uig_set_error((int)e, "conv_rowstrip: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(d.B * d.Ho * (d.Wo / 256)), dim3(256), smem, s, (const T*)x, (const T*)wp, bias, (T*)y, d);
+    UIG_LAUNCH_CHECK("uig_conv_gather(rowstrip)");
+    return 0;
+}
+
+// Returns 1 if this kernel took the launch, 0 if the shape does not qualify (caller falls back).
+int uig_try_conv_rowstrip(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
+                          void* y, int B, int H, int W, int Cin, int Nrows, int k,
+                          int pad_mode, const int* taps, int ntaps, int Ho, int Wo, int ldc, int Nstore, int act, float slope,
+                          int dtype, long x_bytes, long w_bytes, hipStream_t s, int* rc_out) {
+    const int BKe = dtype == UIG_BF16 ? 64 : 32;
+    if (!g_rowstrip_mode || k != 7 || ntaps != 49 || Nrows > 16 || Cin % BKe != 0 || Wo % 256 != 0 || Ho != H || Wo != W) return 0;
+    RowStripDesc d{};
+    d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Ho = Ho; d.Wo = Wo; d.k = k; d.pad_mode = pad_mode;
+    d.Nrows = Nrows; d.ldw = ntaps * Cin; d.ldc = ldc; d.Nstore = Nstore; d.act = act; d.slope = slope;
+    d.x_bytes = (unsigned)x_bytes; d.w_bytes = (unsigned)w_bytes;
+    d.wp2 = wp2; d.bias2 = bias2; d.group_images = group_images;
+    int R = 0;
+    for (int i = 0; i < ntaps; ++i) {
+        d.tap[i] = taps[i];
+        R = std::max(R, std::abs(((taps[i] >> 8) & 255) - 128));
+        if (((taps[i] & 255) - 128) != ((taps[(i / k) * k] & 255) - 128)) return 0;      // taps must be kernel-row major
+    }
+    if (R > (k - 1)) return 0;
+    d.R = R;
+    if (2 * R + 256 > (256 + 7 - 1 + 7) / 8 * 8) return 0;
+    *rc_out = dtype == UIG_BF16 ? launch_rowstrip<bf16_t>(x, wp, bias, y, d, s) : launch_rowstrip<float>(x, wp, bias, y, d, s);
+    return 1;
+}

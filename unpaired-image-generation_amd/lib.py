@@ -24,6 +24,7 @@ SIGNATURES = {
     "uig_device_ok": (_i, []),
     "uig_debug_set_tile": (None, [_i]),
     "uig_debug_set_strip": (None, [_i]),
+    "uig_debug_set_rowstrip": (None, [_i]),
     "uig_debug_set_strip_stamps": (None, [_vp]),
     "uig_conv_gather": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_i, _f, _i, _vp]),
     "uig_conv_gather_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp] + [_i] * 15 + [_i, _f, _i, _vp]),
