@@ -39,13 +39,13 @@ template <> struct MmaR<float> {
     }
 };
 
-template <typename T, int KMAX>
-__global__ __launch_bounds__(256, 2)
+template <typename T, int KMAX, int NW>
+__global__ __launch_bounds__(64 * NW, 2)
 void conv_rowstrip_kernel(const T* __restrict__ x, const T* __restrict__ wp_, const float* __restrict__ bias_, T* __restrict__ y,
                           const RowStripDesc d) {
     constexpr int E = ElemTraits<T>::E;
     constexpr int BK = 8 * E;
-    constexpr int BM = 256, MT = 4;                       // 4 waves x 64 pixels, one 16-channel MFMA column
+    constexpr int BM = 256, MT = BM / (16 * NW);          // NW waves x (256 / NW) pixels, one 16-channel MFMA column
     constexpr int SROWS = (BM + KMAX - 1 + 7) / 8 * 8;    // strip rows (pixels), padded to whole 1-KiB DMA pieces
     constexpr int SPIECES = SROWS / 8;
     constexpr int SBUF = SROWS * 128;
@@ -85,7 +85,7 @@ void conv_rowstrip_kernel(const T* __restrict__ x, const T* __restrict__ wp_, co
         const int rowbase = (img * d.H + hr) * d.W;
         lds_ptr_t sdst = (lds_ptr_t)smem + stage * STAGE;
         const int soff = __builtin_amdgcn_readfirstlane(cc * BK * (int)sizeof(T));
-        for (int j = wave; j < SPIECES; j += 4) {          // strip pieces: rows 8j .. 8j+7 of the strip
+        for (int j = wave; j < SPIECES; j += NW) {          // strip pieces: rows 8j .. 8j+7 of the strip
             const int s = 8 * j + l8;
             const int wi = w0 - R + s;
             const bool win = (unsigned)wi < (unsigned)d.W;
@@ -96,7 +96,7 @@ void conv_rowstrip_kernel(const T* __restrict__ x, const T* __restrict__ wp_, co
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(sdst + j * 1024), 16, (int)off, soff, 0, 0);
         }
         lds_ptr_t wdst = sdst + SBUF;
-        for (int j = wave; j < 2 * k; j += 4) {            // weight pieces: tap kw = j / 2, rows 8 (j % 2) .. + 7
+        for (int j = wave; j < 2 * k; j += NW) {            // weight pieces: tap kw = j / 2, rows 8 (j % 2) .. + 7
             const int kw = j >> 1, n = (j & 1) * 8 + l8;
             const int te = d.tap[kh * k + kw];
             const int csrc = ls ^ ((n >> 1) & 7);
@@ -110,7 +110,7 @@ void conv_rowstrip_kernel(const T* __restrict__ x, const T* __restrict__ wp_, co
     for (int b = 0; b < MT; ++b) acc[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     issue_group(0, 0);
-    const int pl = wave * 64 + l16;                        // this lane's pixel (tile-local) for m-tile 0
+    const int pl = wave * (BM / NW) + l16;                 // this lane's pixel (tile-local) for m-tile 0
     const int wsw = (l16 >> 1) & 7;
     for (int g = 0; g < G; ++g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -121,13 +121,18 @@ void conv_rowstrip_kernel(const T* __restrict__ x, const T* __restrict__ wp_, co
         const unsigned char* sw = sx + SBUF + l16 * 128;
         for (int kw = 0; kw < k; ++kw) {
             const int sft = ((d.tap[kh * k + kw] >> 8) & 255) - 128 + R;      // strip shift of this tap (block-uniform)
+            unsigned xa[MT];                                                   // byte address of chunk half 0; half 1 is ^ 64
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const int s = pl + b * 16 + sft;
+                xa[b] = (unsigned)(s * 128 + ((q ^ ((s >> 1) & 7)) << 4));
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const u32x4_t wf = *reinterpret_cast<const u32x4_t*>(sw + kw * 2048 + (((q + 4 * h) ^ wsw) << 4));
 #pragma unroll
                 for (int b = 0; b < MT; ++b) {
-                    const int s = pl + b * 16 + sft;
-                    const u32x4_t xf = *reinterpret_cast<const u32x4_t*>(sx + s * 128 + (((q + 4 * h) ^ ((s >> 1) & 7)) << 4));
+                    const u32x4_t xf = *reinterpret_cast<const u32x4_t*>(sx + (xa[b] ^ (unsigned)(h << 6)));
                     MmaR<T>::run(wf, xf, acc[b]);
                 }
             }
@@ -165,8 +170,8 @@ void conv_rowstrip_kernel(const T* __restrict__ x, const T* __restrict__ wp_, co
     }
 }
 
-template __global__ void conv_rowstrip_kernel<bf16_t, 7>(const bf16_t*, const bf16_t*, const float*, bf16_t*, const RowStripDesc);
-template __global__ void conv_rowstrip_kernel<float, 7>(const float*, const float*, const float*, float*, const RowStripDesc);
+template __global__ void conv_rowstrip_kernel<bf16_t, 7, 8>(const bf16_t*, const bf16_t*, const float*, bf16_t*, const RowStripDesc);
+template __global__ void conv_rowstrip_kernel<float, 7, 8>(const float*, const float*, const float*, float*, const RowStripDesc);
 
 static int g_rowstrip_mode = 1;
 extern "C" void uig_debug_set_rowstrip(int on) { g_rowstrip_mode = on; }
@@ -175,14 +180,14 @@ template <typename T>
 static int launch_rowstrip(const void* x, const void* wp, const float* bias, void* y, const RowStripDesc& d, hipStream_t s) {
     constexpr int SROWS = (256 + 7 - 1 + 7) / 8 * 8;
     const size_t smem = 2 * (size_t)(SROWS * 128 + 7 * 16 * 128);
-    auto kern = conv_rowstrip_kernel<T, 7>;
+    auto kern = conv_rowstrip_kernel<T, 7, 8>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return uig_set_error((int)e, "conv_rowstrip: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(d.B * d.Ho * (d.Wo / 256)), dim3(256), smem, s, (const T*)x, (const T*)wp, bias, (T*)y, d);
+    hipLaunchKernelGGL(kern, dim3(d.B * d.Ho * (d.Wo / 256)), dim3(512), smem, s, (const T*)x, (const T*)wp, bias, (T*)y, d);
     UIG_LAUNCH_CHECK("uig_conv_gather(rowstrip)");
     return 0;
 }
