@@ -91,6 +91,11 @@ size_t uig_wgrad_workspace_bytes(int Np, int Cq, int kH, int kW, int splits);
  * output tiles, from which the caller chooses `splits`, is ceil(Np / rows) * ceil(kH*kW*Cq / 128). */
 int uig_wgrad_tile_rows(int Np, int Mw, int dtype);
 void uig_debug_set_wgrad_wide(int on);   /* tuning hook: 0 = never use the 256-row tile */
+void uig_debug_set_wgrad_rows(int on);   /* A/B hook: 0 = never use the image-row kernel of the stride-1 3x3 convs */
+/* number of splits (fp32 partial slabs) uig_wgrad_partial should be run with for this shape; target_blocks sizes the grid
+ * of the generic kernel (the image-row kernel of the 3x3 stride-1 convs always runs one block per CU) */
+int uig_wgrad_splits(int B, int Mh, int Mw, int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad,
+                     int dtype, int target_blocks);
 int uig_wgrad_partial(const void* P, const void* Q, float* workspace, int B, int Mh, int Mw, int Np,
                       int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int pad_mode,
                       int splits, int dtype, void* stream);

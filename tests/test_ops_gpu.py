@@ -32,7 +32,8 @@ CONV_CASES = [
     ("conv", 128, 256, 3, 2, 1, "zero", 12, 16, 1),
     ("conv", 256, 256, 3, 1, 1, "reflect", 12, 10, 3),  # ResBlock conv (the 88 % shape), ragged M, padded-gradient + fold dgrad
     ("conv", 256, 256, 3, 1, 1, "reflect", 16, 16, 3),  # square map: strip kernel + direct dgrad with the border-term GEMM
-    ("conv", 128, 256, 3, 1, 1, "reflect", 64, 64, 2),  # the benchmark's 64x64 map (256-pixel strip tiles)
+    ("conv", 128, 256, 3, 1, 1, "reflect", 64, 64, 2),  # the benchmark's 64x64 map (256-pixel strip tiles, image-row wgrad kernel)
+    ("conv", 128, 128, 3, 1, 1, "zero", 6, 64, 3),      # image-row wgrad kernel with zero padding, rows split unevenly
     ("convT", 256, 128, 3, 2, 1, "zero", 6, 8, 2),      # upsample
     ("convT", 128, 64, 3, 2, 1, "zero", 10, 6, 1),
     ("conv", 64, 3, 7, 1, 3, "reflect", 18, 22, 2),     # G head (Cout=3 -> BN=16 tile)
@@ -83,6 +84,30 @@ def test_conv_fwd_bwd(case, dtype):
     assert (dW - wr.grad).abs().max() <= _tol(dtype, wr.grad), f"wgrad L-inf {(dW - wr.grad).abs().max()} of {wr.grad.abs().max()}"
     db = layer.bias.grad.cpu()
     assert (db - br.grad).abs().max() <= _tol(dtype, br.grad) * 2
+
+
+@pytest.mark.parametrize("pm", ["reflect", "zero"])
+def test_wgrad_row_kernel_matches_generic(pm):
+    """bf16 ResBlock weight gradient: the image-row kernel (three kw taps per staged row) against the generic split-K kernel
+    on the same operands - same products, different fp32 summation order."""
+    u, ops, networks = _mods()
+    lib = u.lib.lib()
+    torch.manual_seed(11)
+    layer = networks.ConvLayer("conv", 256, 256, 3, 1, 1, pm, dtype=torch.bfloat16, device="cuda")
+    x = (torch.rand(5, 64, 64, 256, device="cuda") * 2 - 1).to(torch.bfloat16)
+    dy = (torch.randn(5, 64, 64, 256, device="cuda") * 0.5).to(torch.bfloat16)
+    try:
+        lib.uig_debug_set_wgrad_rows(0)
+        ref = ops.conv_wgrad(layer.spec, x, dy)
+    finally:
+        lib.uig_debug_set_wgrad_rows(1)
+    got = ops.conv_wgrad(layer.spec, x, dy)
+    acc = ref.clone()
+    ops.conv_wgrad(layer.spec, x, dy, out=acc, accumulate=True)
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-5 * scale, f"row kernel vs generic: {float((got - ref).abs().max())} of {scale}"
+    assert float((acc - 2 * ref).abs().max()) <= 4e-5 * scale
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])

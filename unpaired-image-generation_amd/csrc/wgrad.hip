@@ -336,6 +336,24 @@ extern "C" int uig_wgrad_tile_rows(int Np, int Mw, int dtype) {
     return Np <= 16 ? 16 : 128;
 }
 
+// wgrad_rows.hip: stride-1 3x3 "same" convs on 64-pixel rows, bf16
+bool uig_wgrad_rows_applicable(int Mh, int Mw, int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int dtype);
+int uig_wgrad_rows_tiles(int Np, int Cq);
+int uig_launch_wgrad_rows(const void* P, const void* Q, float* ws, int B, int H, int Np, int Cq, int pad_mode, int splits, hipStream_t s);
+
+// number of pixel-range splits (= fp32 partial slabs) uig_wgrad_partial should run with for this shape: the kernel it will
+// dispatch to decides (row kernel: one 8-wave block per CU; generic kernel: `target_blocks` 4-wave blocks, two per CU)
+extern "C" int uig_wgrad_splits(int B, int Mh, int Mw, int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad,
+                                int dtype, int target_blocks) {
+    const long M = (long)B * Mh * Mw;
+    if (uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype))
+        return (int)std::max<long>(1, std::min<long>(256 / uig_wgrad_rows_tiles(Np, Cq), (long)B * Mh));
+    const int bn = uig_wgrad_tile_rows(Np, Mw, dtype);
+    const int tiles = ((Np + bn - 1) / bn) * ((kH * kW * Cq + 127) / 128);
+    if (bn >= 256) return (int)std::max<long>(1, std::min<long>(256 / tiles, M / 128));
+    return (int)std::max<long>(1, std::min<long>(std::max(target_blocks, 1) / std::max(tiles, 1), M / 128));
+}
+
 extern "C" int uig_wgrad_partial(const void* P, const void* Q, float* workspace, int B, int Mh, int Mw, int Np,
                                  int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int pad_mode,
                                  int splits, int dtype, void* stream) {
@@ -359,6 +377,8 @@ extern "C" int uig_wgrad_partial(const void* P, const void* Q, float* workspace,
     const long esz = dtype == UIG_BF16 ? 2 : 4;
     d.p_bytes = (unsigned)((long)B * Mh * Mw * Np * esz); d.q_bytes = (unsigned)((long)B * Hq * Wq * Cq * esz);
     hipStream_t s = (hipStream_t)stream;
+    if (uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype) && splits <= B * Mh)
+        return uig_launch_wgrad_rows(P, Q, workspace, B, Mh, Np, Cq, pad_mode, splits, s);
     const int bkp = dtype == UIG_BF16 ? 64 : 32;
     const bool fast = (Mw % bkp) == 0;          // a K-step never leaves its image row (Mper is a multiple of bkp)
     if (g_wgrad_bn256 && Np % 256 == 0 && fast) {       // wide dense tile (the caller halves `splits`: uig_wgrad_tile_rows)

@@ -1,0 +1,291 @@
+// wgrad_rows.hip — weight gradient of the stride-1 3x3 "same" convolutions (the ResBlock convs: 2/3 of the weight-gradient
+// FLOPs of the step) for gfx950, bf16.
+//
+//   part[s][n][(kh*3+kw)*Cq + c] = sum_{image rows R in split s} sum_{j<64} dY[R][j][n] * X[R + kh-1][j + kw-1][c]
+//
+// The generic kernel (wgrad.hip) stages one [64 px][128 ch] tile of each operand per 128x128x64 MMA block: 64 FLOP per
+// staged byte, which is exactly what the L2 -> LDS path of a CU sustains (64 B/clk against 4096 FLOP/clk) - it runs
+// staging-bound at ~560 TFLOP/s.  Here one K-step is ONE IMAGE ROW (W = 64 pixels): a block stages the dY row slice
+// [64 px][128 co] and the X row slice [64 px][128 ci] of input row R+kh-1 once and uses them for all THREE kw taps
+// (fragment reads of the X tile shifted by one pixel row; reflection / zero padding is a per-lane row choice made once),
+// i.e. 192 FLOP per staged byte.  Tiles: (Np/128) x (Cq/128) x 3 (kh); the image rows are split over the rest of the grid
+// and the fp32 partial slabs go to the same deterministic wgrad_reduce kernels as before.
+//
+// Staging is LDS-DMA (buffer_load ... lds, 1 KiB per wave-instruction, four stages, one block barrier per K-step).  The
+// DMA writes LDS linearly, so rows are 256 B with no padding; the 16-byte chunks of row r are XOR-swizzled by 2*(r&7) on
+// the SOURCE address, which makes the ds_read_b64_tr_b16 fragment reads (8 pixel rows x 32 B per 32-lane group)
+// conflict-free.  Both MFMA operands reduce over pixels, the strided index of NHWC: the transposing read delivers them.
+#include "uig_common.h"
+#include <algorithm>
+#include <type_traits>
+
+struct WgRowsDesc {
+    int B, H, Np, Cq, pad_mode;
+    int ncols;               // 9 * Cq
+    int rows_total;          // B * H image rows
+    int ntc, ntiles, splits; // ci tiles, tiles = (Np/128) * ntc * 3
+    unsigned p_bytes, q_bytes;
+};
+
+namespace {
+constexpr int WR_W = 64;                       // pixels per image row = pixels per K-step
+constexpr int WR_TILE = 64 * 256;              // one staged operand tile: 64 pixel rows x 128 channels bf16
+constexpr int WR_STAGE = 2 * WR_TILE + 256;    // dY tile | X tile | one zero row (zero padding of the X columns)
+constexpr int WR_NST = 4;
+}
+
+__global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __restrict__ P, const bf16_t* __restrict__ Q,
+                                                               float* __restrict__ part, const WgRowsDesc d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // XCD-aware order: consecutive logical blocks (the tiles of one split: same image rows) share an XCD and its L2
+    int bid;
+    {
+        const int nwg = gridDim.x, o = blockIdx.x, xcd = o & 7, qq = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + (o >> 3);
+    }
+    const int tile = bid % d.ntiles, split = bid / d.ntiles;
+    const int kh = tile % 3, t2 = tile / 3;
+    const int ci_base = (t2 % d.ntc) * 128, n_base = (t2 / d.ntc) * 128;
+    const int row_begin = (int)((long)split * d.rows_total / d.splits);
+    const int row_end = (int)((long)(split + 1) * d.rows_total / d.splits);
+    const int nk = row_end - row_begin;
+
+    // zero rows (one per stage)
+    if (tid < WR_NST * 16) *reinterpret_cast<u32x4_t*>(smem + (tid >> 4) * WR_STAGE + 2 * WR_TILE + (tid & 15) * 16) = u32x4_t{0u, 0u, 0u, 0u};
+
+    // ---- DMA: wave w stages pieces w and w+8 (rows 4w..4w+3 and +32) of both tiles
+    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(P), 0, d.p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Q), 0, d.q_bytes, 0x00020000);
+    const int ra = 4 * wave + (lane >> 4);                            // pixel (LDS row) this lane fills in piece w
+    const int chunk = (lane & 15) ^ ((ra & 7) << 1);                  // source chunk for LDS slot lane&15 (same for row ra+32)
+    const unsigned voffP = (unsigned)((ra * d.Np + n_base + chunk * 8) * 2);
+    const unsigned voffQ = (unsigned)((ra * d.Cq + ci_base + chunk * 8) * 2);
+    const bool refl = d.pad_mode == UIG_PAD_REFLECT;
+    int ib = row_begin / d.H, ii = row_begin % d.H;                   // (image, row) of the next K-step to issue
+    int Rn = row_begin;
+    auto issue = [&](int stage) {
+        const int hi = ii + kh - 1;
+        const bool valid = refl | ((unsigned)hi < (unsigned)d.H);
+        const int hr = refl ? reflect_idx(hi, d.H) : (valid ? hi : 0);
+        const int sP = __builtin_amdgcn_readfirstlane((int)((unsigned)Rn * (unsigned)(WR_W * 2) * (unsigned)d.Np));
+        const int sQ = __builtin_amdgcn_readfirstlane((int)((unsigned)(ib * d.H + hr) * (unsigned)(WR_W * 2) * (unsigned)d.Cq));
+        const unsigned vq = valid ? voffQ : 0xFFFFFFFFu;              // zero-padded row: out-of-range offset -> zeros
+        lds_ptr_t dst = (lds_ptr_t)smem + stage * WR_STAGE + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (__attribute__((address_space(3))) void*)dst, 16, (int)voffP, sP, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (__attribute__((address_space(3))) void*)(dst + 8192), 16, (int)voffP,
+                                                 sP + 32 * d.Np * 2, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(dst + WR_TILE), 16, (int)vq, sQ, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(dst + WR_TILE + 8192), 16, (int)vq,
+                                                 sQ + 32 * d.Cq * 2, 0, 0);
+        ++Rn;
+        if (++ii == d.H) { ii = 0; ++ib; }
+    };
+
+    // ---- fragment addressing (stage-relative byte offsets).  Wave (wn, wc): 64 co x 32 ci x 3 kw.
+    // ds_read_b64_tr_b16: lane 4q+p of a 16-lane group addresses pixel row 4g+q (+16, +32), channels 4p..4p+3 of a 16-channel
+    // tile, and receives channel l16 of those 4 pixel rows.
+    const int wn = wave & 1, wc = wave >> 1;
+    const int l16 = lane & 15, g = lane >> 4, qq = l16 >> 2, pp = l16 & 3;
+    const int k0 = 4 * g + qq;                                        // pixel of this lane within a 16-pixel group
+    unsigned poff[4];                                                 // dY tile: row k0, co tile b (rows +16 / +32 / +48 are immediates)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        poff[b] = (unsigned)(k0 * 256 + (((wn * 8 + 2 * b + (pp >> 1)) ^ ((k0 & 7) << 1)) << 4) + (pp & 1) * 8);
+    unsigned qoff[3][4][2];                                           // X tile: [kw][16-pixel group][ci tile a]
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int pix = 16 * gq + k0 + kw - 1;
+            const bool inb = (unsigned)pix < (unsigned)WR_W;
+            const int row = refl ? reflect_idx(pix, WR_W) : (inb ? pix : 0);
+            const bool zero = !refl && !inb;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int cidx = wc * 4 + 2 * a + (pp >> 1);
+                qoff[kw][gq][a] = zero ? (unsigned)(2 * WR_TILE + ((cidx & 15) << 4) + (pp & 1) * 8)
+                                       : (unsigned)(WR_TILE + row * 256 + ((cidx ^ ((row & 7) << 1)) << 4) + (pp & 1) * 8);
+            }
+        }
+
+    f32x4_t acc[3][2][4];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[kw][a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // The transposing reads are issued as inline asm: for the builtin form the compiler cannot tell an LDS-DMA write from a
+    // hazard on these reads and drains every in-flight DMA (s_waitcnt vmcnt(0)) before each group of them, which serialises
+    // the whole pipeline (measured: 3100 cycles per K-step instead of ~1700).  The price: their lgkmcnt is ours to wait for
+    // (frags_ready ties the wait to the fragment registers so no MFMA can be scheduled above it).
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+    auto tr_read = [&](unsigned addr, auto off) -> bf16x4_t {
+        u32x2_t r;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(decltype(off)::value));
+        return __builtin_bit_cast(bf16x4_t, r);
+    };
+    // fragment reads in five chunks of four (c = 0,1: dY tiles 2c, 2c+1; c = 2..4: X tap kw = c-2, both ci tiles)
+    auto read_chunk = [&](bf16x8_t (&bf)[4], bf16x8_t (&af)[3][2], unsigned st, auto kgc, int c) {
+        constexpr int kg = decltype(kgc)::value;
+        if (c < 2) {
+#pragma unroll
+            for (int b = 2 * c; b < 2 * c + 2; ++b) {
+                const unsigned pb = st + poff[b];
+                const bf16x4_t lo = tr_read(pb, std::integral_constant<int, kg * 32 * 256>{});
+                const bf16x4_t hi = tr_read(pb, std::integral_constant<int, kg * 32 * 256 + 16 * 256>{});
+                bf[b] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        } else {
+            const int kw = c - 2;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const bf16x4_t lo = tr_read(st + qoff[kw][2 * kg][a], std::integral_constant<int, 0>{});
+                const bf16x4_t hi = tr_read(st + qoff[kw][2 * kg + 1][a], std::integral_constant<int, 0>{});
+                af[kw][a] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        }
+    };
+    auto frags_ready = [&](bf16x8_t (&bf)[4], bf16x8_t (&af)[3][2]) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]),
+                       "+v"(af[1][1]), "+v"(af[2][0]), "+v"(af[2][1]));
+    };
+    auto mma_group = [&](const bf16x8_t (&bf)[4], const bf16x8_t (&af)[3][2], int gi) {      // gi = kw * 2 + a: four MFMAs
+        const int kw = gi >> 1, a = gi & 1;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            acc[kw][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kw][a], bf[b], acc[kw][a][b], 0, 0, 0);
+    };
+
+    // Software pipeline, skewed by half a K-step.  A phase = the 24 MFMAs of one 32-pixel half (six groups of four); the 20
+    // transposing reads of the NEXT half (into the other fragment set) and, in the second phase, the four DMAs of step ks+3
+    // are issued BETWEEN the MFMA groups, so the matrix pipe is fed from the first cycle after the barrier - the two waves
+    // of a SIMD leave the barrier together, and with the reads / DMA issue up front both stalled the pipe for ~700 cycles
+    // per step.  Four stages: the block barrier in the middle of step ks publishes stage ks+1 (read right after it) and
+    // retires stage ks-1, which the DMAs of step ks+3 overwrite - two full steps of flight time for every DMA.
+    bf16x8_t bf0[4], af0[3][2], bf1[4], af1[3][2];
+#ifdef UIG_X_STAMP
+    const unsigned long long xt0 = __builtin_amdgcn_s_memtime(), xr0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long xw_dma = 0, xw_bar = 0;
+#endif
+    if (nk > 0) issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+    if (nk > 0) {
+        if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int c = 0; c < 5; ++c) read_chunk(bf0, af0, lds0, std::integral_constant<int, 0>{}, c);
+    }
+    for (int ks = 0; ks < nk; ++ks) {
+#ifdef UIG_X_FIXST
+        const unsigned st = lds0;
+#else
+        const unsigned st = lds0 + (unsigned)((ks % WR_NST) * WR_STAGE);
+#endif
+        frags_ready(bf0, af0);                             // issued half a step ago: no stall
+#pragma unroll
+        for (int gi = 0; gi < 6; ++gi) {
+            __builtin_amdgcn_sched_barrier(0);
+            mma_group(bf0, af0, gi);
+            __builtin_amdgcn_sched_barrier(0);
+            if (gi < 5) read_chunk(bf1, af1, st, std::integral_constant<int, 1>{}, gi);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        frags_ready(bf1, af1);
+        const bool more = ks + 1 < nk;                     // block-uniform
+        if (more) {
+#ifdef UIG_X_STAMP
+            const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+#endif
+            if (ks + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // stage ks+1 landed; stage ks+2 may still fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef UIG_X_STAMP
+            const unsigned long long w1 = __builtin_amdgcn_s_memtime();
+#endif
+            __builtin_amdgcn_s_barrier();
+#ifdef UIG_X_STAMP
+            const unsigned long long w2 = __builtin_amdgcn_s_memtime();
+            xw_dma += w1 - w0; xw_bar += w2 - w1;
+#endif
+        }
+#ifdef UIG_X_FIXST
+        const unsigned stn = lds0;
+#else
+        const unsigned stn = lds0 + (unsigned)(((ks + 1) % WR_NST) * WR_STAGE);
+#endif
+#pragma unroll
+        for (int gi = 0; gi < 6; ++gi) {
+            __builtin_amdgcn_sched_barrier(0);
+            mma_group(bf1, af1, gi);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more && gi < 5) read_chunk(bf0, af0, stn, std::integral_constant<int, 0>{}, gi);
+#ifndef UIG_X_NODMA
+            if (gi == 4 && ks + 3 < nk) issue((ks + 3) % WR_NST);
+#endif
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+#ifdef UIG_X_STAMP
+    const unsigned long long xt1 = __builtin_amdgcn_s_memtime(), xr1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // D[col][n]: lane holds n = l16 (B-operand column), cols 4g..4g+3 -> one float4 per tile into part[split][n][col]
+    float* out = part + (long)split * d.Np * d.ncols;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int n = n_base + wn * 64 + b * 16 + l16;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int col = (kh * 3 + kw) * d.Cq + ci_base + wc * 32 + a * 16 + 4 * g;
+                *reinterpret_cast<f32x4_t*>(out + (long)n * d.ncols + col) = acc[kw][a][b];
+            }
+    }
+#ifdef UIG_X_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long xt2 = __builtin_amdgcn_s_memtime(), xr2 = __builtin_amdgcn_s_memrealtime();
+    if (tile == 0 && tid == 0) {
+        float* o = part + (long)split * d.Np * d.ncols;
+        o[0] = (float)(xt1 - xt0); o[1] = (float)(xr1 - xr0); o[2] = (float)(xt2 - xt1); o[3] = (float)(xr2 - xr1); o[4] = (float)xw_dma; o[5] = (float)xw_bar;
+    }
+#endif
+}
+
+static int g_wgrad_rows = 1;    // 1 = use this kernel where it applies, 0 = never (A/B and parity hook)
+extern "C" void uig_debug_set_wgrad_rows(int on) { g_wgrad_rows = on; }
+
+// 1 if uig_wgrad_partial runs this launch on the row kernel
+bool uig_wgrad_rows_applicable(int Mh, int Mw, int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int dtype) {
+    return g_wgrad_rows && dtype == UIG_BF16 && kH == 3 && kW == 3 && stride == 1 && pad == 1 && Mh == Hq && Mw == Wq &&
+           Mw == WR_W && Np % 128 == 0 && Cq % 128 == 0 && Hq >= 2;
+}
+
+int uig_wgrad_rows_tiles(int Np, int Cq) { return (Np / 128) * (Cq / 128) * 3; }
+
+int uig_launch_wgrad_rows(const void* P, const void* Q, float* ws, int B, int H, int Np, int Cq, int pad_mode, int splits,
+                          hipStream_t s) {
+    WgRowsDesc d{};
+    d.B = B; d.H = H; d.Np = Np; d.Cq = Cq; d.pad_mode = pad_mode; d.ncols = 9 * Cq; d.rows_total = B * H;
+    d.ntc = Cq / 128; d.ntiles = uig_wgrad_rows_tiles(Np, Cq); d.splits = splits;
+    d.p_bytes = (unsigned)((long)B * H * WR_W * Np * 2); d.q_bytes = (unsigned)((long)B * H * WR_W * Cq * 2);
+    const size_t smem = (size_t)WR_NST * WR_STAGE;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_rows3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return uig_set_error((int)e, "wgrad(rows): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(wgrad_rows3_kernel, dim3(d.ntiles * splits), dim3(512), smem, s, (const bf16_t*)P, (const bf16_t*)Q, ws, d);
+    UIG_LAUNCH_CHECK("uig_wgrad_partial(rows)");
+    return 0;
+}

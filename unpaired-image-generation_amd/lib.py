@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libuig.so")
+LIB_PATH = os.environ.get("UIG_LIB_PATH") or os.path.join(_HERE, "libuig.so")   # UIG_LIB_PATH: A/B a second build of the same ABI
 _lib = None
 
 F32, BF16 = 0, 1
@@ -34,6 +34,8 @@ SIGNATURES = {
     "uig_wgrad_workspace_bytes": (_sz, [_i] * 5),
     "uig_wgrad_tile_rows": (_i, [_i, _i, _i]),
     "uig_debug_set_wgrad_wide": (None, [_i]),
+    "uig_debug_set_wgrad_rows": (None, [_i]),
+    "uig_wgrad_splits": (_i, [_i] * 13),
     "uig_wgrad_partial": (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp]),
     "uig_wgrad_reduce": (_i, [_vp, _vp] + [_i] * 7 + [_vp]),
     "uig_wgrad_reduce_bias": (_i, [_vp, _vp] + [_i] * 7 + [_vp, _i, _i, _i, _vp, _i, _vp]),

@@ -301,10 +301,6 @@ def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, 
 _WGRAD_BLOCKS = int(os.environ.get("UIG_WGRAD_BLOCKS", "512"))   # target grid of the split-K weight-gradient kernel (2 blocks per CU)
 
 
-def _wgrad_splits(tiles: int, M: int) -> int:
-    return max(1, min(_WGRAD_BLOCKS // max(tiles, 1), M // 128))
-
-
 def conv_wgrad(spec: ConvSpec, x: torch.Tensor, dy: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = False,
                bias_rider=None) -> torch.Tensor:
     """aten::convolution_backward, weight gradient (fp32, torch layout).  With `out` the split-K reduce writes (or, with
@@ -321,9 +317,7 @@ def conv_wgrad(spec: ConvSpec, x: torch.Tensor, dy: torch.Tensor, out: torch.Ten
         Pt, Qt, Mh, Mw, Np, Hq, Wq, Cq = x, dy, H, W, spec.cin_p, Ho, Wo, spec.cout_p
         pm = L.PAD_ZERO
         D0, D1 = spec.cin, spec.cout
-    bn = int(lib.uig_wgrad_tile_rows(Np, Mw, _dt(x)))
-    tiles = ((Np + bn - 1) // bn) * ((k * k * Cq + 127) // 128)
-    splits = _wgrad_splits(tiles, B * Mh * Mw) if bn < 256 else max(1, min(256 // tiles, (B * Mh * Mw) // 128))   # 256-row tile: 1 block (8 waves) per CU
+    splits = int(lib.uig_wgrad_splits(B, Mh, Mw, Np, Hq, Wq, Cq, k, k, spec.stride, spec.pad, _dt(x), _WGRAD_BLOCKS))
     ws = torch.empty((splits * Np * k * k * Cq,), device=x.device, dtype=torch.float32)
     L.check(lib.uig_wgrad_partial(_p(Pt), _p(Qt), _p(ws), B, Mh, Mw, Np, Hq, Wq, Cq, k, k, spec.stride, spec.pad, pm,
                                   splits, _dt(x), s), "uig_wgrad_partial")
