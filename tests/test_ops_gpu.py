@@ -110,6 +110,28 @@ def test_wgrad_row_kernel_matches_generic(pm):
     assert float((acc - 2 * ref).abs().max()) <= 4e-5 * scale
 
 
+def test_wgrad_pair_launch_matches_single():
+    """both networks' ResBlock weight-gradient partials from ONE launch (uneven groups: 3 + 2 images) against one launch per
+    network on the image slices"""
+    u, ops, networks = _mods()
+    torch.manual_seed(12)
+    layer = networks.ConvLayer("conv", 128, 256, 3, 1, 1, "reflect", dtype=torch.bfloat16, device="cuda")
+    x = (torch.rand(5, 64, 64, 128, device="cuda") * 2 - 1).to(torch.bfloat16)
+    dy = (torch.randn(5, 64, 64, 256, device="cuda") * 0.5).to(torch.bfloat16)
+    parts = ops.conv_wgrad_pair_partial(layer.spec, x, dy, 3)
+    assert parts is not None, "the image-row kernel should take this shape"
+    for (sl, part) in ((slice(0, 3), parts[0]), (slice(3, 5), parts[1])):
+        got = ops.conv_wgrad(layer.spec, x[sl], dy[sl], partial=part)
+        ref = ops.conv_wgrad(layer.spec, x[sl], dy[sl])
+        torch.cuda.synchronize()
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 2e-5 * scale
+    # a layer the row kernel does not cover reports "no paired launch" instead of guessing
+    l2 = networks.ConvLayer("conv", 64, 128, 3, 2, 1, "zero", dtype=torch.bfloat16, device="cuda")
+    assert ops.conv_wgrad_pair_partial(l2.spec, torch.zeros(4, 32, 32, 64, device="cuda", dtype=torch.bfloat16),
+                                       torch.zeros(4, 16, 16, 128, device="cuda", dtype=torch.bfloat16), 2) is None
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("act", ["tanh", "lrelu"])
 def test_conv_epilogue_activation(act, dtype):

@@ -339,7 +339,7 @@ extern "C" int uig_wgrad_tile_rows(int Np, int Mw, int dtype) {
 // wgrad_rows.hip: stride-1 3x3 "same" convs on 64-pixel rows, bf16
 bool uig_wgrad_rows_applicable(int Mh, int Mw, int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int dtype);
 int uig_wgrad_rows_tiles(int Np, int Cq);
-int uig_launch_wgrad_rows(const void* P, const void* Q, float* ws, int B, int H, int Np, int Cq, int pad_mode, int splits, hipStream_t s);
+int uig_launch_wgrad_rows(const void* P, const void* Q, float* ws, int B, int H, int Np, int Cq, int pad_mode, int splits, int group_images, hipStream_t s);
 
 // number of pixel-range splits (= fp32 partial slabs) uig_wgrad_partial should run with for this shape: the kernel it will
 // dispatch to decides (row kernel: one 8-wave block per CU; generic kernel: `target_blocks` 4-wave blocks, two per CU)
@@ -352,6 +352,30 @@ extern "C" int uig_wgrad_splits(int B, int Mh, int Mw, int Np, int Hq, int Wq, i
     const int tiles = ((Np + bn - 1) / bn) * ((kH * kW * Cq + 127) / 128);
     if (bn >= 256) return (int)std::max<long>(1, std::min<long>(256 / tiles, M / 128));
     return (int)std::max<long>(1, std::min<long>(std::max(target_blocks, 1) / std::max(tiles, 1), M / 128));
+}
+
+// Two networks of identical layer shape in ONE partial launch (images [0, group_images) belong to the first, the rest to the
+// second): twice the output tiles, so half the pixel splits - half the fp32 partial-slab traffic per network, which is what
+// the split-K weight gradient spends most of its time on beyond the MFMAs.  Only where the image-row kernel applies:
+// uig_wgrad_pair_splits returns 0 otherwise and the caller runs the networks one by one.
+// Workspace: [2][splits][Np][kH*kW*Cq] floats; reduce each network's half with uig_wgrad_reduce*.
+extern "C" int uig_wgrad_pair_splits(int B, int group_images, int Mh, int Mw, int Np, int Hq, int Wq, int Cq, int kH, int kW,
+                                     int stride, int pad, int dtype) {
+    if (group_images <= 0 || group_images >= B) return 0;
+    if (!uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype)) return 0;
+    const long rows = (long)std::min(group_images, B - group_images) * Mh;
+    return (int)std::max<long>(1, std::min<long>(256 / (2 * uig_wgrad_rows_tiles(Np, Cq)), rows));
+}
+extern "C" int uig_wgrad_partial_pair(const void* P, const void* Q, float* workspace, int B, int group_images, int Mh, int Mw,
+                                      int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int pad_mode,
+                                      int splits, int dtype, void* stream) {
+    UIG_CHECK_ARG(P && Q && workspace, "uig_wgrad_partial_pair: null pointer");
+    UIG_CHECK_ARG(group_images > 0 && group_images < B, "uig_wgrad_partial_pair: bad group_images %d of %d", group_images, B);
+    UIG_CHECK_ARG(uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype),
+                  "uig_wgrad_partial_pair: shape not supported (query uig_wgrad_pair_splits)");
+    UIG_CHECK_ARG(splits >= 1 && splits <= std::min(group_images, B - group_images) * Mh, "uig_wgrad_partial_pair: bad splits %d", splits);
+    UIG_CHECK_ARG((long)B * Mh * Mw * Np * 2 < (1L << 32) - 64 && (long)B * Hq * Wq * Cq * 2 < (1L << 32) - 64, "uig_wgrad_partial_pair: tensor too large for 32-bit byte offsets");
+    return uig_launch_wgrad_rows(P, Q, workspace, B, Mh, Np, Cq, pad_mode, splits, group_images, (hipStream_t)stream);
 }
 
 extern "C" int uig_wgrad_partial(const void* P, const void* Q, float* workspace, int B, int Mh, int Mw, int Np,
@@ -378,7 +402,7 @@ extern "C" int uig_wgrad_partial(const void* P, const void* Q, float* workspace,
     d.p_bytes = (unsigned)((long)B * Mh * Mw * Np * esz); d.q_bytes = (unsigned)((long)B * Hq * Wq * Cq * esz);
     hipStream_t s = (hipStream_t)stream;
     if (uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype) && splits <= B * Mh)
-        return uig_launch_wgrad_rows(P, Q, workspace, B, Mh, Np, Cq, pad_mode, splits, s);
+        return uig_launch_wgrad_rows(P, Q, workspace, B, Mh, Np, Cq, pad_mode, splits, 0, s);
     const int bkp = dtype == UIG_BF16 ? 64 : 32;
     const bool fast = (Mw % bkp) == 0;          // a K-step never leaves its image row (Mper is a multiple of bkp)
     if (g_wgrad_bn256 && Np % 256 == 0 && fast) {       // wide dense tile (the caller halves `splits`: uig_wgrad_tile_rows)

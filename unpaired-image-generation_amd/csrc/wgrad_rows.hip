@@ -23,7 +23,9 @@ struct WgRowsDesc {
     int B, H, Np, Cq, pad_mode;
     int ncols;               // 9 * Cq
     int rows_total;          // B * H image rows
-    int ntc, ntiles, splits; // ci tiles, tiles = (Np/128) * ntc * 3
+    int ntc, ntiles, splits; // ci tiles, tiles per network = (Np/128) * ntc * 3
+    int group_rows;          // two networks in one launch: image rows [0, group_rows) are network 0's, the rest network 1's
+                             // (0 = one network); partial slabs are laid out [network][split][Np][ncols]
     unsigned p_bytes, q_bytes;
 };
 
@@ -47,11 +49,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
         const int nwg = gridDim.x, o = blockIdx.x, xcd = o & 7, qq = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + (o >> 3);
     }
-    const int tile = bid % d.ntiles, split = bid / d.ntiles;
+    const int nets = d.group_rows > 0 ? 2 : 1;
+    const int tile2 = bid % (d.ntiles * nets), split = bid / (d.ntiles * nets);
+    const int net = tile2 / d.ntiles, tile = tile2 % d.ntiles;
     const int kh = tile % 3, t2 = tile / 3;
     const int ci_base = (t2 % d.ntc) * 128, n_base = (t2 / d.ntc) * 128;
-    const int row_begin = (int)((long)split * d.rows_total / d.splits);
-    const int row_end = (int)((long)(split + 1) * d.rows_total / d.splits);
+    const int net_row0 = net ? d.group_rows : 0;
+    const int net_rows = nets == 1 ? d.rows_total : (net ? d.rows_total - d.group_rows : d.group_rows);
+    const int row_begin = net_row0 + (int)((long)split * net_rows / d.splits);
+    const int row_end = net_row0 + (int)((long)(split + 1) * net_rows / d.splits);
     const int nk = row_end - row_begin;
 
     // zero rows (one per stage)
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
     const unsigned long long xt1 = __builtin_amdgcn_s_memtime(), xr1 = __builtin_amdgcn_s_memrealtime();
 #endif
     // D[col][n]: lane holds n = l16 (B-operand column), cols 4g..4g+3 -> one float4 per tile into part[split][n][col]
-    float* out = part + (long)split * d.Np * d.ncols;
+    float* out = part + ((long)net * d.splits + split) * d.Np * d.ncols;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const int n = n_base + wn * 64 + b * 16 + l16;
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long xt2 = __builtin_amdgcn_s_memtime(), xr2 = __builtin_amdgcn_s_memrealtime();
     if (tile == 0 && tid == 0) {
-        float* o = part + (long)split * d.Np * d.ncols;
+        float* o = part + ((long)net * d.splits + split) * d.Np * d.ncols;
         o[0] = (float)(xt1 - xt0); o[1] = (float)(xr1 - xr0); o[2] = (float)(xt2 - xt1); o[3] = (float)(xr2 - xr1); o[4] = (float)xw_dma; o[5] = (float)xw_bar;
     }
 #endif
@@ -273,8 +279,9 @@ bool uig_wgrad_rows_applicable(int Mh, int Mw, int Np, int Hq, int Wq, int Cq, i
 int uig_wgrad_rows_tiles(int Np, int Cq) { return (Np / 128) * (Cq / 128) * 3; }
 
 int uig_launch_wgrad_rows(const void* P, const void* Q, float* ws, int B, int H, int Np, int Cq, int pad_mode, int splits,
-                          hipStream_t s) {
+                          int group_images, hipStream_t s) {
     WgRowsDesc d{};
+    d.group_rows = group_images * H;
     d.B = B; d.H = H; d.Np = Np; d.Cq = Cq; d.pad_mode = pad_mode; d.ncols = 9 * Cq; d.rows_total = B * H;
     d.ntc = Cq / 128; d.ntiles = uig_wgrad_rows_tiles(Np, Cq); d.splits = splits;
     d.p_bytes = (unsigned)((long)B * H * WR_W * Np * 2); d.q_bytes = (unsigned)((long)B * H * WR_W * Cq * 2);
@@ -285,7 +292,7 @@ int uig_launch_wgrad_rows(const void* P, const void* Q, float* ws, int B, int H,
         if (e != hipSuccess) return uig_set_error((int)e, "wgrad(rows): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL(wgrad_rows3_kernel, dim3(d.ntiles * splits), dim3(512), smem, s, (const bf16_t*)P, (const bf16_t*)Q, ws, d);
+    hipLaunchKernelGGL(wgrad_rows3_kernel, dim3(d.ntiles * splits * (group_images > 0 ? 2 : 1)), dim3(512), smem, s, (const bf16_t*)P, (const bf16_t*)Q, ws, d);
     UIG_LAUNCH_CHECK("uig_wgrad_partial(rows)");
     return 0;
 }

@@ -43,6 +43,8 @@ class CycleGAN:
         self.use_graph, self.batch_fused, self.paired = use_graph, batch_fused, paired
         # parameter-gradient kernels stay on the side stream across layers and are joined once per phase (see ops.deferred_param_grads)
         self.defer_join = os.environ.get("UIG_DEFER_JOIN", "1") != "0"
+        # generator update (exchange wait, Adam, repack) on its own stream under the discriminator phase (0: after it, on the main stream)
+        self.overlap_update = os.environ.get("UIG_OVERLAP_UPDATE", "1") != "0"
         self._graphs = None
         self._finalize_params()
 
@@ -66,12 +68,29 @@ class CycleGAN:
                     own[k].copy_(v.to(self.device, torch.float32))
         self.repack()
 
-    def repack(self):
-        """refresh every layer's kernel-side weight operands from the fp32 master copy: one launch for all four networks"""
-        mp = getattr(self, "_packer", None)
+    def _packer_of(self, which):
+        """one-launch weight packer of an optimiser group's networks ('G' or 'D'); rebuilt if buffers were re-allocated"""
+        packers = self.__dict__.setdefault("_packers", {})
+        mp = packers.get(which)
         if mp is None or not mp.valid():
-            mp = self._packer = ops.MultiPacker([l for n in self.nets() for l in n.conv_layers()])
-        mp.run()
+            nets = (self.G_A, self.G_B) if which == "G" else (self.D_A, self.D_B)
+            mp = packers[which] = ops.MultiPacker([l for n in nets for l in n.conv_layers()])
+        return mp
+
+    def repack(self):
+        """refresh every layer's kernel-side weight operands (packed bf16/fp32 tiles) from the fp32 master copy.  The train
+        step keeps them current itself (each Adam is followed by the repack of its group); call this after writing
+        parameters from outside."""
+        self._packer_of("G").run()
+        self._packer_of("D").run()
+
+    def _update_stream(self):
+        if not self.overlap_update:
+            return torch.cuda.current_stream(self.device)
+        st = self.__dict__.get("_upd_stream")
+        if st is None:
+            st = self._upd_stream = torch.cuda.Stream(device=self.device)
+        return st
 
     def broadcast_params(self, src=0):
         self.xchg.broadcast(self.grp_G.flat, src)
@@ -145,15 +164,28 @@ class CycleGAN:
 
     # ------------------------------------------------------------------ the step
     def _step_eager(self, xa, xb):
-        self.repack()
+        """Stream plan: the generator update (gradient exchange, Adam, repack of the generators' kernel operands) does not
+        depend on the discriminator phase and the discriminator phase does not read the generators' weights, so the update
+        runs on its own stream UNDER the discriminators' forward+backward (it was ~0.45 ms of the critical path)."""
+        main, upd = torch.cuda.current_stream(self.device), self._update_stream()
         fake_B, fake_A, lg = self._g_phase(xa, xb)
         h_g = self.xchg.start(self.grp_G.grad)           # overlaps the whole discriminator phase
+        if self.overlap_update:
+            upd.wait_stream(main)
+            with torch.cuda.stream(upd):
+                self.xchg.wait(h_g, self.device)
+                self._adam(self.grp_G)
+                self._packer_of("G").run()
         ld = self._d_phase(xa, xb, fake_B, fake_A)
-        self.xchg.wait(h_g, self.device)
-        h_d = self.xchg.start(self.grp_D.grad)           # overlaps the generator Adam
-        self._adam(self.grp_G)
+        if not self.overlap_update:
+            self.xchg.wait(h_g, self.device)
+            self._adam(self.grp_G)
+            self._packer_of("G").run()
+        h_d = self.xchg.start(self.grp_D.grad)
         self.xchg.wait(h_d, self.device)
         self._adam(self.grp_D)
+        self._packer_of("D").run()
+        main.wait_stream(upd)
         l_D_A = ld[0][0] + ld[0][1]
         l_D_B = ld[1][0] + ld[1][1]
         return torch.cat(lg + [l_D_A, l_D_B])

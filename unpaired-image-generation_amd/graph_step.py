@@ -1,6 +1,7 @@
 """HIP-graph execution of the train step: the static-shape, sync-free step is captured once into four graphs
-(G fwd+bwd | D fwd+bwd | Adam G | Adam D) and replayed; data-parallel all-reduces are enqueued between the replays on
-the communication stream, so the generator exchange overlaps the discriminators' forward+backward.
+(G fwd+bwd | D fwd+bwd | Adam G + repack G | Adam D + repack D) and replayed; data-parallel all-reduces are enqueued
+between the replays on the communication stream and the generator update graph is replayed on its own stream, so the
+generator exchange, Adam and weight repack all run under the discriminators' forward+backward.
 Replaces a tracing compiler: one capture of the hand-written kernel sequence, no per-op host overhead afterwards."""
 from __future__ import annotations
 
@@ -37,10 +38,10 @@ def _capture(model, real_A, real_B):
         for t in (g.flat, g.m, g.v):
             t.copy_(next(it))
     model.grp_G.step, model.grp_D.step = steps
+    model.repack()                                   # the warm-up step left the kernel operands at its own updated weights
 
     st.g1, st.g2, st.g3, st.g4 = (torch.cuda.CUDAGraph() for _ in range(4))
     with torch.cuda.graph(st.g1):
-        model.repack()
         st.xa, st.xb = model.to_phys(st.real_A), model.to_phys(st.real_B)
         st.fake_B, st.fake_A, lg = model._g_phase(st.xa, st.xb)
         st.lg = torch.cat([l.detach() for l in lg])
@@ -51,9 +52,11 @@ def _capture(model, real_A, real_B):
     with torch.cuda.graph(st.g3, pool=pool):
         g = model.grp_G
         ops.adam_flat_graph(g.flat, g.grad, g.m, g.v, model.lr, model.b1, model.b2, model.eps, g.state16, 1.0 / model.world)
+        model._packer_of("G").run()
     with torch.cuda.graph(st.g4, pool=pool):
         g = model.grp_D
         ops.adam_flat_graph(g.flat, g.grad, g.m, g.v, model.lr, model.b1, model.b2, model.eps, g.state16, 1.0 / model.world)
+        model._packer_of("D").run()
     return st
 
 
@@ -72,14 +75,22 @@ def graph_train_step(model, real_A, real_B):
             return model._step_eager(model.to_phys(real_A), model.to_phys(real_B))
     st.real_A.copy_(real_A, non_blocking=True)
     st.real_B.copy_(real_B, non_blocking=True)
+    main, upd = torch.cuda.current_stream(model.device), model._update_stream()
     st.g1.replay()
-    h_g = model.xchg.start(model.grp_G.grad)      # overlaps the discriminator graph
+    h_g = model.xchg.start(model.grp_G.grad)      # exchange, Adam and repack of the generators run under the discriminator graph
+    if model.overlap_update:
+        upd.wait_stream(main)
+        with torch.cuda.stream(upd):
+            model.xchg.wait(h_g, model.device)
+            st.g3.replay()
     st.g2.replay()
-    model.xchg.wait(h_g, model.device)
-    h_d = model.xchg.start(model.grp_D.grad)      # overlaps the generator Adam
-    st.g3.replay()
+    if not model.overlap_update:
+        model.xchg.wait(h_g, model.device)
+        st.g3.replay()
+    h_d = model.xchg.start(model.grp_D.grad)
     model.xchg.wait(h_d, model.device)
     st.g4.replay()
+    main.wait_stream(upd)
     model.grp_G.step += 1
     model.grp_D.step += 1
     return st.losses

@@ -17,6 +17,7 @@ from . import lib as L
 
 
 REFLECT_DGRAD_DIRECT = os.environ.get("UIG_REFLECT_DGRAD_DIRECT", "1") != "0"   # 3x3 reflect-pad convs: input gradient on the exact grid + border GEMM (no padded gradient, no fold)
+PAIR_WGRAD = os.environ.get("UIG_PAIR_WGRAD", "1") != "0"                   # paired layers: both networks' weight-gradient partials in one launch where the library supports it
 PARALLEL_BACKWARD = os.environ.get("UIG_PARALLEL_BACKWARD", "1") != "0"      # run a conv's parameter-gradient kernels concurrently with its input-gradient kernel
 _SIDE_STREAMS = {}
 _DEFER_JOIN = {}
@@ -301,10 +302,31 @@ def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, 
 _WGRAD_BLOCKS = int(os.environ.get("UIG_WGRAD_BLOCKS", "512"))   # target grid of the split-K weight-gradient kernel (2 blocks per CU)
 
 
+def conv_wgrad_pair_partial(spec: ConvSpec, x: torch.Tensor, dy: torch.Tensor, group: int):
+    """Partial weight-gradient slabs of TWO networks (first `group` images / the rest) in one launch, or None where the
+    library has no paired kernel for this layer.  Returns [(workspace of network i, splits)] for conv_wgrad(partial=...)."""
+    if spec.kind != "conv":
+        return None
+    lib = L.lib()
+    B, H, W, _ = x.shape
+    _, Ho, Wo, _ = dy.shape
+    k = spec.k
+    splits = int(lib.uig_wgrad_pair_splits(B, group, Ho, Wo, spec.cout_p, H, W, spec.cin_p, k, k, spec.stride, spec.pad, _dt(x)))
+    if splits <= 0:
+        return None
+    per = splits * spec.cout_p * k * k * spec.cin_p
+    ws = torch.empty((2 * per,), device=x.device, dtype=torch.float32)
+    pm = L.PAD_REFLECT if spec.reflect else L.PAD_ZERO
+    L.check(lib.uig_wgrad_partial_pair(_p(dy), _p(x), _p(ws), B, group, Ho, Wo, spec.cout_p, H, W, spec.cin_p, k, k, spec.stride,
+                                       spec.pad, pm, splits, _dt(x), _stream()), "uig_wgrad_partial_pair")
+    return [(ws[:per], splits), (ws[per:], splits)]
+
+
 def conv_wgrad(spec: ConvSpec, x: torch.Tensor, dy: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = False,
-               bias_rider=None) -> torch.Tensor:
+               bias_rider=None, partial=None) -> torch.Tensor:
     """aten::convolution_backward, weight gradient (fp32, torch layout).  With `out` the split-K reduce writes (or, with
-    accumulate=True, adds) straight into that tensor, e.g. the layer's slice of the flat gradient buffer."""
+    accumulate=True, adds) straight into that tensor, e.g. the layer's slice of the flat gradient buffer.
+    partial = (workspace, splits) from conv_wgrad_pair_partial: only the reduce runs."""
     lib, s = L.lib(), _stream()
     B, H, W, _ = x.shape
     _, Ho, Wo, _ = dy.shape
@@ -317,10 +339,13 @@ def conv_wgrad(spec: ConvSpec, x: torch.Tensor, dy: torch.Tensor, out: torch.Ten
         Pt, Qt, Mh, Mw, Np, Hq, Wq, Cq = x, dy, H, W, spec.cin_p, Ho, Wo, spec.cout_p
         pm = L.PAD_ZERO
         D0, D1 = spec.cin, spec.cout
-    splits = int(lib.uig_wgrad_splits(B, Mh, Mw, Np, Hq, Wq, Cq, k, k, spec.stride, spec.pad, _dt(x), _WGRAD_BLOCKS))
-    ws = torch.empty((splits * Np * k * k * Cq,), device=x.device, dtype=torch.float32)
-    L.check(lib.uig_wgrad_partial(_p(Pt), _p(Qt), _p(ws), B, Mh, Mw, Np, Hq, Wq, Cq, k, k, spec.stride, spec.pad, pm,
-                                  splits, _dt(x), s), "uig_wgrad_partial")
+    if partial is not None:
+        ws, splits = partial
+    else:
+        splits = int(lib.uig_wgrad_splits(B, Mh, Mw, Np, Hq, Wq, Cq, k, k, spec.stride, spec.pad, _dt(x), _WGRAD_BLOCKS))
+        ws = torch.empty((splits * Np * k * k * Cq,), device=x.device, dtype=torch.float32)
+        L.check(lib.uig_wgrad_partial(_p(Pt), _p(Qt), _p(ws), B, Mh, Mw, Np, Hq, Wq, Cq, k, k, spec.stride, spec.pad, pm,
+                                      splits, _dt(x), s), "uig_wgrad_partial")
     if out is None:
         out, accumulate = torch.empty(spec.weight_shape(), device=x.device, dtype=torch.float32), False
     elif not (out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == tuple(spec.weight_shape())):
@@ -354,7 +379,7 @@ def _bias_grad_from_partials(cs, img0, nimg, nreal, out, accumulate):
     return out
 
 
-def _param_grads(layer, spec, x, dy, need_w, need_b, colsum=None, img0=0):
+def _param_grads(layer, spec, x, dy, need_w, need_b, colsum=None, img0=0, partial=None):
     """dW / db of one layer.  When the parameter already owns a .grad buffer (the trainer's flat gradient buffer, or any
     earlier backward) the reduce kernels ADD into it in place and autograd gets None (= nothing more to accumulate):
     gradient-accumulation fusion, no temporary dW and no extra add kernel.  Otherwise they are returned the usual way."""
@@ -367,9 +392,9 @@ def _param_grads(layer, spec, x, dy, need_w, need_b, colsum=None, img0=0):
     if need_w:
         w = layer.weight
         if layer.fuse_grad_accum and w.grad is not None and w.grad.is_contiguous():
-            conv_wgrad(spec, x, dy, out=w.grad, accumulate=True, bias_rider=rider)
+            conv_wgrad(spec, x, dy, out=w.grad, accumulate=True, bias_rider=rider, partial=partial)
         else:
-            dW = conv_wgrad(spec, x, dy, bias_rider=rider)
+            dW = conv_wgrad(spec, x, dy, bias_rider=rider, partial=partial)
     if need_b:
         b = layer.bias
         fused = layer.fuse_grad_accum and b.grad is not None and b.grad.is_contiguous()
@@ -417,12 +442,13 @@ def _conv_backward(ctx, dy, layers, group):
         side = _side_stream(dy.device)
         side.wait_stream(main)
     with (torch.cuda.stream(side) if par else contextlib.nullcontext()):
+        pparts = conv_wgrad_pair_partial(spec, x, dy, group) if (npar == 2 and all(need_w) and PAIR_WGRAD) else None
         for i, layer in enumerate(layers):
             if npar == 1:
                 xs, dys, i0 = x, dy, 0
             else:
                 xs, dys, i0 = (x[:group], dy[:group], 0) if i == 0 else (x[group:], dy[group:], group)
-            grads.extend(_param_grads(layer, spec, xs, dys, need_w[i], need_b[i], colsum, i0))
+            grads.extend(_param_grads(layer, spec, xs, dys, need_w[i], need_b[i], colsum, i0, pparts[i] if pparts else None))
     if par:
         if need_x:
             dx = conv_dgrad(spec, dy, layers[0].wp_dgrad, ctx.in_hw, pair)
