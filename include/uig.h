@@ -100,11 +100,11 @@ int uig_wgrad_partial(const void* P, const void* Q, float* workspace, int B, int
                       int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int pad_mode,
                       int splits, int dtype, void* stream);
 /* dW[d0][d1][tap] (+)= sum_s part[s][d0][tap][d1]  for d0 < D0, d1 < D1 (the real, unpadded channel counts) */
-/* Two networks of the same layer shape in one partial launch (images [0, group_images) are the first network's): half the
- * splits, so half the partial-slab traffic per network.  uig_wgrad_pair_splits returns 0 where this is not supported (then run
- * the networks one by one).  Workspace [2][splits][Np][kH*kW*Cq] floats; reduce each half with uig_wgrad_reduce*. */
+/* Two networks of the same layer shape in one partial launch (images [0, group_images) are the first network's): twice the
+ * tiles, so half the splits and half the partial-slab traffic per network.  uig_wgrad_pair_splits returns the split count to
+ * use (0 = bad grouping).  Workspace [2][splits][Np][kH*kW*Cq] floats; reduce each half with uig_wgrad_reduce*. */
 int uig_wgrad_pair_splits(int B, int group_images, int Mh, int Mw, int Np, int Hq, int Wq, int Cq, int kH, int kW,
-                          int stride, int pad, int dtype);
+                          int stride, int pad, int dtype, int target_blocks);
 int uig_wgrad_partial_pair(const void* P, const void* Q, float* workspace, int B, int group_images, int Mh, int Mw,
                            int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int pad_mode,
                            int splits, int dtype, void* stream);

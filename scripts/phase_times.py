@@ -25,3 +25,21 @@ report('pre+Gfwd', win[:g_first])
 report('G bwd', win[g_last + 1:d_first if False else None] if False else [k for k in win[g_last + 1:] if k['s'] < win[d_first]['s'] and win.index(k) < d_first - 40])
 report('G bwd..D fwd', win[g_last + 1:d_first])
 report('D bwd..', win[d_last + 1:])
+
+# coarse timeline of the whole step: per 0.5 ms bucket, busy fraction of each queue and the dominant kernel
+print()
+qs = sorted({k['Queue_Id'] for k in win})
+bucket = 500_000
+nb = int((t1 - t0 + bucket - 1) // bucket)
+for b in range(nb):
+    a, e = t0 + b * bucket, t0 + (b + 1) * bucket
+    line = f"{b * 0.5:5.1f} ms "
+    dom = collections.Counter()
+    for q in qs:
+        busy = sum(max(0, min(k['e'], e) - max(k['s'], a)) for k in win if k['Queue_Id'] == q)
+        line += f" q{q}:{100 * busy / bucket:3.0f}%"
+    for k in win:
+        ov = max(0, min(k['e'], e) - max(k['s'], a))
+        if ov: dom[k['n'][:28]] += ov
+    line += "  " + ", ".join(f"{n} {v / bucket * 100:.0f}" for n, v in dom.most_common(3))
+    print(line)

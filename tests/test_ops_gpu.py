@@ -126,10 +126,19 @@ def test_wgrad_pair_launch_matches_single():
         torch.cuda.synchronize()
         scale = float(ref.abs().max())
         assert float((got - ref).abs().max()) <= 2e-5 * scale
-    # a layer the row kernel does not cover reports "no paired launch" instead of guessing
-    l2 = networks.ConvLayer("conv", 64, 128, 3, 2, 1, "zero", dtype=torch.bfloat16, device="cuda")
-    assert ops.conv_wgrad_pair_partial(l2.spec, torch.zeros(4, 32, 32, 64, device="cuda", dtype=torch.bfloat16),
-                                       torch.zeros(4, 16, 16, 128, device="cuda", dtype=torch.bfloat16), 2) is None
+    # layers on the generic split-K kernel (stride-2 conv, transposed conv, 4x4 discriminator conv; fp32 and bf16)
+    for kind, cin, cout, k, st, pm, H, dt in (("conv", 64, 128, 3, 2, "zero", 32, torch.bfloat16), ("convT", 128, 64, 3, 2, "zero", 16, torch.float32),
+                                              ("conv", 64, 128, 4, 2, "zero", 32, torch.bfloat16), ("conv", 64, 3, 7, 1, "reflect", 24, torch.float32)):
+        l2 = networks.ConvLayer(kind, cin, cout, k, st, 3 if k == 7 else 1, pm, dtype=dt, device="cuda")
+        x2 = (torch.rand(5, H, H, l2.spec.cin_p, device="cuda") * 2 - 1).to(dt)
+        Ho, Wo = l2.spec.out_hw(H, H)
+        dy2 = (torch.randn(5, Ho, Wo, l2.spec.cout_p, device="cuda") * 0.5).to(dt)
+        parts = ops.conv_wgrad_pair_partial(l2.spec, x2, dy2, 2)
+        for (sl, part) in ((slice(0, 2), parts[0]), (slice(2, 5), parts[1])):
+            got = ops.conv_wgrad(l2.spec, x2[sl], dy2[sl], partial=part)
+            ref = ops.conv_wgrad(l2.spec, x2[sl], dy2[sl])
+            torch.cuda.synchronize()
+            assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (kind, cin, cout, k)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])

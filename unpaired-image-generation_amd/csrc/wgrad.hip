@@ -18,6 +18,8 @@ struct WgradDesc {
     int kW, taps, stride, pad, pad_mode;
     int ncols;               // taps * Cq
     int M, Mper;             // pixels total, pixels per split (multiple of 32)
+    int group_M, splits;     // two networks in one launch (group_M > 0): pixels [0, group_M) are network 0's; gridDim.y = 2 * splits and
+                             // the partial slabs are laid out [network][split]
     unsigned p_bytes, q_bytes;
 };
 
@@ -48,8 +50,11 @@ __global__ __launch_bounds__((BN >= 256 ? 512 : 256), 2) void wgrad_kernel(const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntn = (d.Np + BN - 1) / BN;
     const int n_base = (blockIdx.x % ntn) * BN, col_base = (blockIdx.x / ntn) * BC;
-    const int m_begin = blockIdx.y * d.Mper;
-    const int m_end = min(d.M, m_begin + d.Mper);
+    const int net = d.group_M > 0 ? (int)blockIdx.y / d.splits : 0;
+    const int split = d.group_M > 0 ? (int)blockIdx.y % d.splits : (int)blockIdx.y;
+    const int net_m0 = net ? d.group_M : 0, net_m1 = (d.group_M > 0 && !net) ? d.group_M : d.M;
+    const int m_begin = net_m0 + split * d.Mper;
+    const int m_end = min(net_m1, m_begin + d.Mper);
     const int nk = (m_end > m_begin) ? (m_end - m_begin + BKP - 1) / BKP : 0;
 
     // fixed per-thread chunk columns
@@ -322,7 +327,7 @@ static int launch_wgrad(const void* P, const void* Q, float* ws, const WgradDesc
         attr_done = true;
     }
     const int ntn = (d.Np + BN - 1) / BN, ntc = (d.ncols + 127) / 128;
-    hipLaunchKernelGGL(kern, dim3(ntn * ntc, splits), dim3(BN >= 256 ? 512 : 256), smem, s, (const T*)P, (const T*)Q, ws, d);
+    hipLaunchKernelGGL(kern, dim3(ntn * ntc, splits * (d.group_M > 0 ? 2 : 1)), dim3(BN >= 256 ? 512 : 256), smem, s, (const T*)P, (const T*)Q, ws, d);
     UIG_LAUNCH_CHECK("uig_wgrad_partial");
     return 0;
 }
@@ -354,34 +359,11 @@ extern "C" int uig_wgrad_splits(int B, int Mh, int Mw, int Np, int Hq, int Wq, i
     return (int)std::max<long>(1, std::min<long>(std::max(target_blocks, 1) / std::max(tiles, 1), M / 128));
 }
 
-// Two networks of identical layer shape in ONE partial launch (images [0, group_images) belong to the first, the rest to the
-// second): twice the output tiles, so half the pixel splits - half the fp32 partial-slab traffic per network, which is what
-// the split-K weight gradient spends most of its time on beyond the MFMAs.  Only where the image-row kernel applies:
-// uig_wgrad_pair_splits returns 0 otherwise and the caller runs the networks one by one.
-// Workspace: [2][splits][Np][kH*kW*Cq] floats; reduce each network's half with uig_wgrad_reduce*.
-extern "C" int uig_wgrad_pair_splits(int B, int group_images, int Mh, int Mw, int Np, int Hq, int Wq, int Cq, int kH, int kW,
-                                     int stride, int pad, int dtype) {
-    if (group_images <= 0 || group_images >= B) return 0;
-    if (!uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype)) return 0;
-    const long rows = (long)std::min(group_images, B - group_images) * Mh;
-    return (int)std::max<long>(1, std::min<long>(256 / (2 * uig_wgrad_rows_tiles(Np, Cq)), rows));
-}
-extern "C" int uig_wgrad_partial_pair(const void* P, const void* Q, float* workspace, int B, int group_images, int Mh, int Mw,
-                                      int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int pad_mode,
-                                      int splits, int dtype, void* stream) {
-    UIG_CHECK_ARG(P && Q && workspace, "uig_wgrad_partial_pair: null pointer");
-    UIG_CHECK_ARG(group_images > 0 && group_images < B, "uig_wgrad_partial_pair: bad group_images %d of %d", group_images, B);
-    UIG_CHECK_ARG(uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype),
-                  "uig_wgrad_partial_pair: shape not supported (query uig_wgrad_pair_splits)");
-    UIG_CHECK_ARG(splits >= 1 && splits <= std::min(group_images, B - group_images) * Mh, "uig_wgrad_partial_pair: bad splits %d", splits);
-    UIG_CHECK_ARG((long)B * Mh * Mw * Np * 2 < (1L << 32) - 64 && (long)B * Hq * Wq * Cq * 2 < (1L << 32) - 64, "uig_wgrad_partial_pair: tensor too large for 32-bit byte offsets");
-    return uig_launch_wgrad_rows(P, Q, workspace, B, Mh, Np, Cq, pad_mode, splits, group_images, (hipStream_t)stream);
-}
-
-extern "C" int uig_wgrad_partial(const void* P, const void* Q, float* workspace, int B, int Mh, int Mw, int Np,
-                                 int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int pad_mode,
-                                 int splits, int dtype, void* stream) {
+static int wgrad_partial_impl(const void* P, const void* Q, float* workspace, int B, int group_images, int Mh, int Mw, int Np,
+                              int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int pad_mode,
+                              int splits, int dtype, void* stream) {
     UIG_CHECK_ARG(P && Q && workspace, "uig_wgrad_partial: null pointer");
+    UIG_CHECK_ARG(group_images >= 0 && group_images < B, "uig_wgrad_partial: bad group_images %d of %d", group_images, B);
     UIG_CHECK_ARG(Np % 8 == 0 && Cq % 8 == 0 && Np > 0 && Cq > 0, "uig_wgrad_partial: channels must be padded to 8 (Np=%d Cq=%d)", Np, Cq);
     UIG_CHECK_ARG(splits >= 1 && splits <= 65535, "uig_wgrad_partial: bad splits %d", splits);
     UIG_CHECK_ARG(stride == 1 || stride == 2, "uig_wgrad_partial: stride=%d unsupported", stride);
@@ -397,12 +379,15 @@ extern "C" int uig_wgrad_partial(const void* P, const void* Q, float* workspace,
     d.B = B; d.Mh = Mh; d.Mw = Mw; d.Np = Np; d.Hq = Hq; d.Wq = Wq; d.Cq = Cq;
     d.kW = kW; d.taps = kH * kW; d.stride = stride; d.pad = pad; d.pad_mode = pad_mode;
     d.ncols = kH * kW * Cq; d.M = B * Mh * Mw;
-    d.Mper = ((d.M + splits - 1) / splits + 63) / 64 * 64;
+    d.group_M = group_images * Mh * Mw; d.splits = splits;
+    const int M_net = group_images > 0 ? std::max(d.group_M, d.M - d.group_M) : d.M;
+    d.Mper = ((M_net + splits - 1) / splits + 63) / 64 * 64;
     const long esz = dtype == UIG_BF16 ? 2 : 4;
     d.p_bytes = (unsigned)((long)B * Mh * Mw * Np * esz); d.q_bytes = (unsigned)((long)B * Hq * Wq * Cq * esz);
     hipStream_t s = (hipStream_t)stream;
-    if (uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype) && splits <= B * Mh)
-        return uig_launch_wgrad_rows(P, Q, workspace, B, Mh, Np, Cq, pad_mode, splits, 0, s);
+    if (uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype) &&
+        splits <= (group_images > 0 ? std::min(group_images, B - group_images) : B) * Mh)
+        return uig_launch_wgrad_rows(P, Q, workspace, B, Mh, Np, Cq, pad_mode, splits, group_images, s);
     const int bkp = dtype == UIG_BF16 ? 64 : 32;
     const bool fast = (Mw % bkp) == 0;          // a K-step never leaves its image row (Mper is a multiple of bkp)
     if (g_wgrad_bn256 && Np % 256 == 0 && fast) {       // wide dense tile (the caller halves `splits`: uig_wgrad_tile_rows)
@@ -415,6 +400,34 @@ extern "C" int uig_wgrad_partial(const void* P, const void* Q, float* workspace,
     }
     if (Np <= 16) return fast ? launch_wgrad<float, 16, true>(P, Q, workspace, d, splits, s) : launch_wgrad<float, 16, false>(P, Q, workspace, d, splits, s);
     return fast ? launch_wgrad<float, 128, true>(P, Q, workspace, d, splits, s) : launch_wgrad<float, 128, false>(P, Q, workspace, d, splits, s);
+}
+
+extern "C" int uig_wgrad_partial(const void* P, const void* Q, float* workspace, int B, int Mh, int Mw, int Np,
+                                 int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int pad_mode,
+                                 int splits, int dtype, void* stream) {
+    return wgrad_partial_impl(P, Q, workspace, B, 0, Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, pad_mode, splits, dtype, stream);
+}
+
+// Two networks of identical layer shape in ONE partial launch (images [0, group_images) belong to the first, the rest to the
+// second): twice the output tiles, so half the pixel splits - half the fp32 partial-slab traffic per network, which is what
+// the split-K weight gradient spends most of its time on beyond the MFMAs.
+// Workspace: [2][splits][Np][kH*kW*Cq] floats; reduce each network's half with uig_wgrad_reduce*.
+extern "C" int uig_wgrad_pair_splits(int B, int group_images, int Mh, int Mw, int Np, int Hq, int Wq, int Cq, int kH, int kW,
+                                     int stride, int pad, int dtype, int target_blocks) {
+    if (group_images <= 0 || group_images >= B) return 0;
+    const int gmin = std::min(group_images, B - group_images);
+    if (uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype))
+        return (int)std::max<long>(1, std::min<long>(256 / (2 * uig_wgrad_rows_tiles(Np, Cq)), (long)gmin * Mh));
+    const int bn = uig_wgrad_tile_rows(Np, Mw, dtype);
+    const int tiles = 2 * ((Np + bn - 1) / bn) * ((kH * kW * Cq + 127) / 128);
+    const long M_net = (long)gmin * Mh * Mw;
+    return (int)std::max<long>(1, std::min<long>((bn >= 256 ? 256 : std::max(target_blocks, 1)) / tiles, M_net / 128));
+}
+extern "C" int uig_wgrad_partial_pair(const void* P, const void* Q, float* workspace, int B, int group_images, int Mh, int Mw,
+                                      int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int pad_mode,
+                                      int splits, int dtype, void* stream) {
+    UIG_CHECK_ARG(group_images > 0 && group_images < B, "uig_wgrad_partial_pair: bad group_images %d of %d", group_images, B);
+    return wgrad_partial_impl(P, Q, workspace, B, group_images, Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, pad_mode, splits, dtype, stream);
 }
 
 static int wgrad_reduce_impl(const float* workspace, float* dW, int Np, int Cq, int taps, int splits, int D0, int D1, int accumulate,

@@ -37,7 +37,7 @@ SIGNATURES = {
     "uig_debug_set_wgrad_rows": (None, [_i]),
     "uig_wgrad_splits": (_i, [_i] * 13),
     "uig_wgrad_partial": (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp]),
-    "uig_wgrad_pair_splits": (_i, [_i] * 13),
+    "uig_wgrad_pair_splits": (_i, [_i] * 14),
     "uig_wgrad_partial_pair": (_i, [_vp, _vp, _vp] + [_i] * 15 + [_vp]),
     "uig_wgrad_reduce": (_i, [_vp, _vp] + [_i] * 7 + [_vp]),
     "uig_wgrad_reduce_bias": (_i, [_vp, _vp] + [_i] * 7 + [_vp, _i, _i, _i, _vp, _i, _vp]),

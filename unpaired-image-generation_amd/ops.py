@@ -302,23 +302,28 @@ def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, 
 _WGRAD_BLOCKS = int(os.environ.get("UIG_WGRAD_BLOCKS", "512"))   # target grid of the split-K weight-gradient kernel (2 blocks per CU)
 
 
-def conv_wgrad_pair_partial(spec: ConvSpec, x: torch.Tensor, dy: torch.Tensor, group: int):
-    """Partial weight-gradient slabs of TWO networks (first `group` images / the rest) in one launch, or None where the
-    library has no paired kernel for this layer.  Returns [(workspace of network i, splits)] for conv_wgrad(partial=...)."""
-    if spec.kind != "conv":
-        return None
-    lib = L.lib()
+def _wgrad_operands(spec: ConvSpec, x: torch.Tensor, dy: torch.Tensor):
+    """(dense P, gathered Q, Mh, Mw, Np, Hq, Wq, Cq, pad mode, D0, D1) of the weight-gradient GEMM"""
     B, H, W, _ = x.shape
     _, Ho, Wo, _ = dy.shape
-    k = spec.k
-    splits = int(lib.uig_wgrad_pair_splits(B, group, Ho, Wo, spec.cout_p, H, W, spec.cin_p, k, k, spec.stride, spec.pad, _dt(x)))
+    if spec.kind == "conv":      # dense = dy, gathered = x;  dW (Cout, Cin, k, k)
+        return dy, x, Ho, Wo, spec.cout_p, H, W, spec.cin_p, (L.PAD_REFLECT if spec.reflect else L.PAD_ZERO), spec.cout, spec.cin
+    return x, dy, H, W, spec.cin_p, Ho, Wo, spec.cout_p, L.PAD_ZERO, spec.cin, spec.cout      # convT: dense = x, gathered = dy
+
+
+def conv_wgrad_pair_partial(spec: ConvSpec, x: torch.Tensor, dy: torch.Tensor, group: int):
+    """Partial weight-gradient slabs of TWO networks (first `group` images / the rest) in one launch.
+    Returns [(workspace of network i, splits)] for conv_wgrad(partial=...)."""
+    lib = L.lib()
+    B, k = x.shape[0], spec.k
+    Pt, Qt, Mh, Mw, Np, Hq, Wq, Cq, pm, _, _ = _wgrad_operands(spec, x, dy)
+    splits = int(lib.uig_wgrad_pair_splits(B, group, Mh, Mw, Np, Hq, Wq, Cq, k, k, spec.stride, spec.pad, _dt(x), _WGRAD_BLOCKS))
     if splits <= 0:
         return None
-    per = splits * spec.cout_p * k * k * spec.cin_p
+    per = splits * Np * k * k * Cq
     ws = torch.empty((2 * per,), device=x.device, dtype=torch.float32)
-    pm = L.PAD_REFLECT if spec.reflect else L.PAD_ZERO
-    L.check(lib.uig_wgrad_partial_pair(_p(dy), _p(x), _p(ws), B, group, Ho, Wo, spec.cout_p, H, W, spec.cin_p, k, k, spec.stride,
-                                       spec.pad, pm, splits, _dt(x), _stream()), "uig_wgrad_partial_pair")
+    L.check(lib.uig_wgrad_partial_pair(_p(Pt), _p(Qt), _p(ws), B, group, Mh, Mw, Np, Hq, Wq, Cq, k, k, spec.stride, spec.pad, pm,
+                                       splits, _dt(x), _stream()), "uig_wgrad_partial_pair")
     return [(ws[:per], splits), (ws[per:], splits)]
 
 
@@ -328,17 +333,8 @@ def conv_wgrad(spec: ConvSpec, x: torch.Tensor, dy: torch.Tensor, out: torch.Ten
     accumulate=True, adds) straight into that tensor, e.g. the layer's slice of the flat gradient buffer.
     partial = (workspace, splits) from conv_wgrad_pair_partial: only the reduce runs."""
     lib, s = L.lib(), _stream()
-    B, H, W, _ = x.shape
-    _, Ho, Wo, _ = dy.shape
-    k = spec.k
-    if spec.kind == "conv":      # dense = dy, gathered = x;  dW (Cout, Cin, k, k)
-        Pt, Qt, Mh, Mw, Np, Hq, Wq, Cq = dy, x, Ho, Wo, spec.cout_p, H, W, spec.cin_p
-        pm = L.PAD_REFLECT if spec.reflect else L.PAD_ZERO
-        D0, D1 = spec.cout, spec.cin
-    else:                        # dense = x, gathered = dy;  dW (Cin, Cout, k, k)
-        Pt, Qt, Mh, Mw, Np, Hq, Wq, Cq = x, dy, H, W, spec.cin_p, Ho, Wo, spec.cout_p
-        pm = L.PAD_ZERO
-        D0, D1 = spec.cin, spec.cout
+    B, k = x.shape[0], spec.k
+    Pt, Qt, Mh, Mw, Np, Hq, Wq, Cq, pm, D0, D1 = _wgrad_operands(spec, x, dy)
     if partial is not None:
         ws, splits = partial
     else:
