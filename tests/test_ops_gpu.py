@@ -110,6 +110,32 @@ def test_wgrad_row_kernel_matches_generic(pm):
     assert float((acc - 2 * ref).abs().max()) <= 4e-5 * scale
 
 
+@pytest.mark.parametrize("pm,H,W", [("reflect", 24, 256), ("reflect", 10, 72), ("zero", 12, 40)])
+def test_wgrad_head_kernel_matches_generic(pm, H, W):
+    """bf16 weight gradient of the 7x7 64 -> 3 output conv: the image-row kernel (kw taps as operand columns, halo pixels as
+    extra LDS rows) against the generic split-K kernel, single launch and paired launch"""
+    u, ops, networks = _mods()
+    lib = u.lib.lib()
+    torch.manual_seed(13)
+    layer = networks.ConvLayer("conv", 64, 3, 7, 1, 3, pm, dtype=torch.bfloat16, device="cuda")
+    x = (torch.rand(5, H, W, 64, device="cuda") * 2 - 1).to(torch.bfloat16)
+    dy = torch.zeros(5, H, W, 8, device="cuda", dtype=torch.bfloat16)
+    dy[..., :3] = (torch.randn(5, H, W, 3, device="cuda") * 0.5).to(torch.bfloat16)
+    try:
+        lib.uig_debug_set_wgrad_head(0)
+        ref = ops.conv_wgrad(layer.spec, x, dy)
+        refs = [ops.conv_wgrad(layer.spec, x[:2], dy[:2]), ops.conv_wgrad(layer.spec, x[2:], dy[2:])]
+    finally:
+        lib.uig_debug_set_wgrad_head(1)
+    got = ops.conv_wgrad(layer.spec, x, dy)
+    parts = ops.conv_wgrad_pair_partial(layer.spec, x, dy, 2)
+    gots = [ops.conv_wgrad(layer.spec, x[:2], dy[:2], partial=parts[0]), ops.conv_wgrad(layer.spec, x[2:], dy[2:], partial=parts[1])]
+    torch.cuda.synchronize()
+    for g_, r_ in [(got, ref)] + list(zip(gots, refs)):
+        scale = float(r_.abs().max())
+        assert float((g_ - r_).abs().max()) <= 2e-5 * scale, f"head kernel vs generic: {float((g_ - r_).abs().max())} of {scale}"
+
+
 def test_wgrad_pair_launch_matches_single():
     """both networks' ResBlock weight-gradient partials from ONE launch (uneven groups: 3 + 2 images) against one launch per
     network on the image slices"""

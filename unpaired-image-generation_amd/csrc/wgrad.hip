@@ -345,6 +345,9 @@ extern "C" int uig_wgrad_tile_rows(int Np, int Mw, int dtype) {
 bool uig_wgrad_rows_applicable(int Mh, int Mw, int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int dtype);
 int uig_wgrad_rows_tiles(int Np, int Cq);
 int uig_launch_wgrad_rows(const void* P, const void* Q, float* ws, int B, int H, int Np, int Cq, int pad_mode, int splits, int group_images, hipStream_t s);
+// wgrad_head.hip: 7x7 stride-1 pad-3 convs with 64 input and <= 8 (padded) output channels, bf16
+bool uig_wgrad_head_applicable(int Mh, int Mw, int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int dtype);
+int uig_launch_wgrad_head(const void* P, const void* Q, float* ws, int B, int H, int W, int Np, int pad_mode, int splits, int group_images, hipStream_t s);
 
 // number of pixel-range splits (= fp32 partial slabs) uig_wgrad_partial should run with for this shape: the kernel it will
 // dispatch to decides (row kernel: one 8-wave block per CU; generic kernel: `target_blocks` 4-wave blocks, two per CU)
@@ -353,6 +356,8 @@ extern "C" int uig_wgrad_splits(int B, int Mh, int Mw, int Np, int Hq, int Wq, i
     const long M = (long)B * Mh * Mw;
     if (uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype))
         return (int)std::max<long>(1, std::min<long>(256 / uig_wgrad_rows_tiles(Np, Cq), (long)B * Mh));
+    if (uig_wgrad_head_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype))
+        return (int)std::max<long>(1, std::min<long>(256 / 7, (long)B * Mh));
     const int bn = uig_wgrad_tile_rows(Np, Mw, dtype);
     const int tiles = ((Np + bn - 1) / bn) * ((kH * kW * Cq + 127) / 128);
     if (bn >= 256) return (int)std::max<long>(1, std::min<long>(256 / tiles, M / 128));
@@ -388,6 +393,9 @@ static int wgrad_partial_impl(const void* P, const void* Q, float* workspace, in
     if (uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype) &&
         splits <= (group_images > 0 ? std::min(group_images, B - group_images) : B) * Mh)
         return uig_launch_wgrad_rows(P, Q, workspace, B, Mh, Np, Cq, pad_mode, splits, group_images, s);
+    if (uig_wgrad_head_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype) &&
+        splits <= (group_images > 0 ? std::min(group_images, B - group_images) : B) * Mh)
+        return uig_launch_wgrad_head(P, Q, workspace, B, Mh, Mw, Np, pad_mode, splits, group_images, s);
     const int bkp = dtype == UIG_BF16 ? 64 : 32;
     const bool fast = (Mw % bkp) == 0;          // a K-step never leaves its image row (Mper is a multiple of bkp)
     if (g_wgrad_bn256 && Np % 256 == 0 && fast) {       // wide dense tile (the caller halves `splits`: uig_wgrad_tile_rows)
@@ -418,6 +426,8 @@ extern "C" int uig_wgrad_pair_splits(int B, int group_images, int Mh, int Mw, in
     const int gmin = std::min(group_images, B - group_images);
     if (uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype))
         return (int)std::max<long>(1, std::min<long>(256 / (2 * uig_wgrad_rows_tiles(Np, Cq)), (long)gmin * Mh));
+    if (uig_wgrad_head_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype))
+        return (int)std::max<long>(1, std::min<long>(256 / 14, (long)gmin * Mh));
     const int bn = uig_wgrad_tile_rows(Np, Mw, dtype);
     const int tiles = 2 * ((Np + bn - 1) / bn) * ((kH * kW * Cq + 127) / 128);
     const long M_net = (long)gmin * Mh * Mw;
