@@ -128,7 +128,9 @@ int uig_pack_weight(const float* w, void* wp, int D0, int D1, int kH, int kW, in
 
 /* Every layer of every network in one launch.  items_dev: device array of nitems 48-byte records
  * {const float* w; void* dst; int D0, D1, taps, row_dim, rows_padded, cols_padded; int64 work_end} where work_end is the
- * inclusive prefix sum of rows_padded*taps*cols_padded; total_work = the last work_end. */
+ * inclusive prefix sum of uig_pack_tiles(...) of the records (one block transposes one tile); total_work = the last
+ * work_end.  rows_padded must equal the real row count (only the column dimension is zero padded); taps <= 64. */
+int uig_pack_tiles(int D0, int D1, int kH, int kW, int row_dim, int rows_padded, int cols_padded);
 int uig_pack_weights_multi(const void* items_dev, int nitems, int64_t total_work, int dtype, void* stream);
 
 /* aten::instance_norm(use_input_stats=True, weight=None, eps) fused with ReLU / LeakyReLU and residual add:

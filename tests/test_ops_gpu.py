@@ -136,6 +136,29 @@ def test_wgrad_head_kernel_matches_generic(pm, H, W):
         assert float((g_ - r_).abs().max()) <= 2e-5 * scale, f"head kernel vs generic: {float((g_ - r_).abs().max())} of {scale}"
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_multi_packer_matches_per_layer_pack(dtype):
+    """one-launch tile-transposing weight packer (all layers of a generator and a discriminator) against the per-layer
+    reference kernel: both kernel-side operands of every layer, bit for bit"""
+    u, ops, networks = _mods()
+    torch.manual_seed(21)
+    nets = (networks.Generator(n_blocks=2, dtype=dtype, device="cuda"), networks.Discriminator(dtype=dtype, device="cuda"))
+    layers = [l for n in nets for l in n.conv_layers()]
+    with torch.no_grad():
+        for l in layers:
+            l.weight.normal_(0, 0.05)
+    for l in layers:
+        l.repack()                                   # per-layer kernel
+    want = [(l.wp_fwd.clone(), l.wp_dgrad.clone()) for l in layers]
+    for l in layers:
+        l.wp_fwd.fill_(7.0); l.wp_dgrad.fill_(7.0)
+    ops.MultiPacker(layers).run()
+    torch.cuda.synchronize()
+    for l, (f, d) in zip(layers, want):
+        assert torch.equal(l.wp_fwd, f), f"fwd operand of {l.spec}"
+        assert torch.equal(l.wp_dgrad, d), f"dgrad operand of {l.spec}"
+
+
 def test_wgrad_pair_launch_matches_single():
     """both networks' ResBlock weight-gradient partials from ONE launch (uneven groups: 3 + 2 images) against one launch per
     network on the image slices"""

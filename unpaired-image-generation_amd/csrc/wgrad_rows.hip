@@ -192,11 +192,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
         for (int c = 0; c < 5; ++c) read_chunk(bf0, af0, lds0, std::integral_constant<int, 0>{}, c);
     }
     for (int ks = 0; ks < nk; ++ks) {
-#ifdef UIG_X_FIXST
-        const unsigned st = lds0;
-#else
         const unsigned st = lds0 + (unsigned)((ks % WR_NST) * WR_STAGE);
-#endif
         frags_ready(bf0, af0);                             // issued half a step ago: no stall
 #pragma unroll
         for (int gi = 0; gi < 6; ++gi) {
@@ -223,11 +219,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
             xw_dma += w1 - w0; xw_bar += w2 - w1;
 #endif
         }
-#ifdef UIG_X_FIXST
-        const unsigned stn = lds0;
-#else
         const unsigned stn = lds0 + (unsigned)(((ks + 1) % WR_NST) * WR_STAGE);
-#endif
 #pragma unroll
         for (int gi = 0; gi < 6; ++gi) {
             __builtin_amdgcn_sched_barrier(0);

@@ -178,7 +178,10 @@ class MultiPacker:
                 ops_ = ((l.wp_fwd, L.PACK_ROW_DIM1, sp.cout, sp.cin_p), (l.wp_dgrad, L.PACK_ROW_DIM0, sp.cin, sp.cout_p))
             for dst, rd, rows, cols in ops_:
                 assert dst.numel() == rows * t * cols
-                end += rows * t * cols
+                nt = int(L.lib().uig_pack_tiles(D0, D1, sp.k, sp.k, rd, rows, cols))
+                if nt <= 0:
+                    raise ValueError(f"uig_pack_tiles: unsupported weight shape {tuple(w.shape)}")
+                end += nt
                 recs.append((w.data_ptr(), dst.data_ptr(), D0, D1, t, rd, rows, cols, end))
         self.total = end
         self.ptrs = [(l.weight.data_ptr(), l.wp_fwd.data_ptr(), l.wp_dgrad.data_ptr()) for l in self.layers]
