@@ -178,7 +178,8 @@ int uig_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float
                   float eps, int step, float grad_scale, void* stream);
 
 /* Same update, replayable from a HIP graph: the step counter and bias-correction scalars live in the 16-byte device
- * record state16 = {int step; float lr/bc1; float 1/sqrt(bc2); pad}; each call increments step on the device. */
+ * record state16 = {int step; float lr*lr_scale/bc1; float 1/sqrt(bc2); float lr_scale}; each call increments step on
+ * the device.  lr_scale (the LR schedule's multiplier) is written by the host between replays; initialise it to 1.0f. */
 int uig_adam_flat_graph(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                         float eps, void* state16, float grad_scale, void* stream);
 

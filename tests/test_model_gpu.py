@@ -129,6 +129,54 @@ def test_graph_replay_equals_eager():
     assert torch.equal(me.grp_G.flat, mg.grp_G.flat) and torch.equal(me.grp_D.flat, mg.grp_D.flat)
 
 
+def test_schedule_pool_and_checkpoint_graph_equals_eager(tmp_path):
+    """§8(f) rows 1-2 on the device: the LR-schedule multiplier reaches the graph-replayed Adam through its device record,
+    the image pools feed the discriminator graph through static buffers, and a checkpoint resumes bit-identically."""
+    import unpaired_image_generation_amd as u
+    torch.manual_seed(31)
+    batches = [tuple(torch.rand(2, 3, 64, 64, device="cuda") * 2 - 1 for _ in range(2)) for _ in range(5)]
+    torch.manual_seed(6)
+    me = u.CycleGAN(n_blocks=6, dtype=torch.bfloat16, use_graph=False, pool_size=3, pool_seed=4)
+    mg = u.CycleGAN(n_blocks=6, dtype=torch.bfloat16, use_graph=True, pool_size=3, pool_seed=4)
+    mg.load_state_dicts(*[n.state_dict() for n in me.nets()])
+    w0 = me.grp_G.flat.clone()
+    for step, (rA, rB) in enumerate(batches[:3]):
+        if step == 2:
+            me.set_epoch(150, 100, 100); mg.set_epoch(150, 100, 100)      # LR x (1 - 50/101)
+        le = me.train_step(rA, rB); lg = mg.train_step(rA, rB)
+        assert le == lg, (step, le, lg)
+    assert torch.equal(me.grp_G.flat, mg.grp_G.flat) and torch.equal(me.grp_D.flat, mg.grp_D.flat)
+    assert not torch.equal(me.grp_G.flat, w0)
+    assert me.pool_B.n == 3 and torch.equal(me.pool_B.buf, mg.pool_B.buf)
+    # checkpoint from the graph model -> a fresh eager model resumes exactly where both are
+    path = str(tmp_path / "ckpt.pt")
+    mg.save(path)
+    torch.manual_seed(123)
+    mr = u.CycleGAN(n_blocks=6, dtype=torch.bfloat16, use_graph=False, pool_size=3, pool_seed=77)
+    mr.load(path)
+    assert mr.lr_scale == me.lr_scale and mr.grp_G.step == 3
+    for rA, rB in batches[3:]:
+        le = me.train_step(rA, rB); lr_ = mr.train_step(rA, rB); lg = mg.train_step(rA, rB)
+        assert le == lr_ == lg
+    assert torch.equal(me.grp_G.flat, mr.grp_G.flat) and torch.equal(me.grp_D.m, mr.grp_D.m)
+
+
+def test_lr_scale_scales_the_update():
+    """Adam's first step moves every weight by lr * scale (bias-corrected m / sqrt(v) = +-1): halving the multiplier halves it."""
+    import unpaired_image_generation_amd as u
+    torch.manual_seed(8)
+    rA, rB = (torch.rand(1, 3, 64, 64, device="cuda") * 2 - 1 for _ in range(2))
+    deltas = []
+    for scale, graph in ((1.0, False), (0.5, False), (0.5, True)):
+        torch.manual_seed(9)
+        m = u.CycleGAN(n_blocks=6, dtype=torch.bfloat16, use_graph=graph)
+        w0 = m.grp_D.flat.clone()
+        m.set_lr_scale(scale)
+        m.train_step(rA, rB)
+        deltas.append((m.grp_D.flat - w0).abs().max().item())
+    assert abs(deltas[0] - 2e-4) < 2e-6 and abs(deltas[1] - 1e-4) < 1e-6 and abs(deltas[2] - 1e-4) < 1e-6, deltas
+
+
 def test_train_step_gradients_vs_oracle_fp32():
     """The whole backward path at once: after one §3.1 step, every parameter gradient (G_A, G_B, D_A, D_B) vs the
     oracle's autograd on the same weights and inputs.  fp32 path; relative L2 error per tensor < 1e-2 (measured worst ~3e-3, on the 7x7 stem whose gradient crosses the whole net).

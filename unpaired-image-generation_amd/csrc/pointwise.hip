@@ -336,12 +336,13 @@ extern "C" int uig_adam_flat(float* p, const float* g, float* m, float* v, int64
 }
 
 // Graph-replayable form: the step counter and the bias-correction scalars live in a 16-byte device record
-// state = {int step; float lr/bc1; float 1/sqrt(bc2); pad}; every call increments step on the device first.
+// state = {int step; float lr*scale/bc1; float 1/sqrt(bc2); float lr_scale}; every call increments step on the device first.
+// lr_scale is the schedule's multiplier: the host writes it into the record between replays (no re-capture).
 __global__ void adam_tick_kernel(int* st, float lr, float b1, float b2) {
     const int s = st[0] + 1;
     st[0] = s;
     const double bc1 = 1.0 - pow((double)b1, (double)s), bc2 = 1.0 - pow((double)b2, (double)s);
-    reinterpret_cast<float*>(st)[1] = (float)((double)lr / bc1);
+    reinterpret_cast<float*>(st)[1] = (float)((double)lr * (double)reinterpret_cast<float*>(st)[3] / bc1);
     reinterpret_cast<float*>(st)[2] = (float)(1.0 / sqrt(bc2));
 }
 extern "C" int uig_adam_flat_graph(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -24,6 +24,7 @@ import torch
 from . import ops
 from .dp import FlatGroup, GradExchange
 from .networks import Discriminator, Generator, pair_forward_phys
+from .schedule import ImagePool, linear_decay_scale
 
 LOSS_NAMES = ("idt_A", "idt_B", "G_A", "G_B", "cyc_A", "cyc_B", "D_A", "D_B")
 
@@ -31,12 +32,15 @@ LOSS_NAMES = ("idt_A", "idt_B", "G_A", "G_B", "cyc_A", "cyc_B", "D_A", "D_B")
 class CycleGAN:
     def __init__(self, n_blocks=9, dtype=torch.bfloat16, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-8,
                  lambda_cyc=10.0, lambda_idt=0.5, device="cuda", process_group=None, use_graph=False, batch_fused=True, paired=True,
-                 force_exchange=False):
+                 force_exchange=False, pool_size=0, pool_seed=0):
         self.device, self.dtype = torch.device(device), dtype
         kw = dict(dtype=dtype, device=device)
         self.G_A, self.G_B = Generator(n_blocks=n_blocks, **kw), Generator(n_blocks=n_blocks, **kw)
         self.D_A, self.D_B = Discriminator(**kw), Discriminator(**kw)
         self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        self.lr_scale = 1.0                               # LR-schedule multiplier (set_lr_scale / set_epoch)
+        # image history pools feeding the discriminators' fake batch (§8f row 1); size 0 (default, parity / bench) = off
+        self.pool_B, self.pool_A = ImagePool(pool_size, pool_seed), ImagePool(pool_size, pool_seed + 1)
         self.lam, self.lam_idt = lambda_cyc, lambda_idt
         self.xchg = GradExchange(process_group, force=force_exchange)
         self.world = self.xchg.world
@@ -160,7 +164,54 @@ class CycleGAN:
 
     def _adam(self, grp):
         grp.step += 1
-        ops.adam_flat(grp.flat, grp.grad, grp.m, grp.v, self.lr, self.b1, self.b2, self.eps, grp.step, 1.0 / self.world)
+        ops.adam_flat(grp.flat, grp.grad, grp.m, grp.v, self.lr * self.lr_scale, self.b1, self.b2, self.eps, grp.step, 1.0 / self.world)
+
+    # ------------------------------------------------------------------ schedule / pool / checkpoint (§8f rows 1-2)
+    def set_lr_scale(self, scale: float):
+        """LR-schedule multiplier for the following steps (both optimisers).  In graph mode it is written into the Adam
+        device records, so the captured graphs keep replaying - no re-capture."""
+        self.lr_scale = float(scale)
+        for grp in (self.grp_G, self.grp_D):
+            st = getattr(grp, "state16", None)
+            if st is not None:
+                st.view(torch.float32)[3:4].fill_(self.lr_scale)
+
+    def set_epoch(self, epoch: int, n_const: int = 100, n_decay: int = 100):
+        """constant LR for n_const epochs, then linear decay to zero over n_decay epochs [PAPER]"""
+        self.set_lr_scale(linear_decay_scale(epoch, n_const, n_decay))
+
+    def _pool_fakes(self, fake_B, fake_A, out_B=None, out_A=None):
+        return self.pool_B.query(fake_B, out_B), self.pool_A.query(fake_A, out_A)
+
+    def state_dict(self):
+        """Everything needed to resume: the four networks (stock-torch state_dict keys), both Adam states, schedule, pools."""
+        torch.cuda.synchronize(self.device)
+        sd = {"nets": [{k: v.detach().clone() for k, v in n.state_dict().items()} for n in self.nets()],
+              "lr_scale": self.lr_scale, "pool_B": self.pool_B.state_dict(), "pool_A": self.pool_A.state_dict()}
+        for name, grp in (("G", self.grp_G), ("D", self.grp_D)):
+            step = grp.step
+            st = getattr(grp, "state16", None)
+            if st is not None:                              # graph mode keeps the authoritative counter on the device
+                step = int(st[0].item())
+            sd["opt_" + name] = {"m": grp.m.clone(), "v": grp.v.clone(), "step": step}
+        return sd
+
+    def load_state_dict(self, sd):
+        self.load_state_dicts(*sd["nets"])
+        for name, grp in (("G", self.grp_G), ("D", self.grp_D)):
+            o = sd["opt_" + name]
+            grp.m.copy_(o["m"]); grp.v.copy_(o["v"]); grp.step = int(o["step"])
+            st = getattr(grp, "state16", None)
+            if st is not None:
+                st[0] = grp.step
+        self.pool_B.load_state_dict(sd["pool_B"]); self.pool_A.load_state_dict(sd["pool_A"])
+        self.set_lr_scale(sd.get("lr_scale", 1.0))
+
+    def save(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load(self, path):
+        self.load_state_dict(torch.load(path, map_location=self.device, weights_only=True))      # tensors, ints, floats, tuples only
 
     # ------------------------------------------------------------------ the step
     def _step_eager(self, xa, xb):
@@ -176,6 +227,7 @@ class CycleGAN:
                 self.xchg.wait(h_g, self.device)
                 self._adam(self.grp_G)
                 self._packer_of("G").run()
+        fake_B, fake_A = self._pool_fakes(fake_B, fake_A)
         ld = self._d_phase(xa, xb, fake_B, fake_A)
         if not self.overlap_update:
             self.xchg.wait(h_g, self.device)

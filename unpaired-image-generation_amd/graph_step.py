@@ -22,11 +22,13 @@ def _capture(model, real_A, real_B):
     for grp in (model.grp_G, model.grp_D):
         if not hasattr(grp, "state16"):
             grp.state16 = torch.zeros(4, device=dev, dtype=torch.int32)
-            grp.state16[0] = grp.step
+            grp.state16.view(torch.float32)[3] = model.lr_scale      # {step, lr*scale/bc1, 1/sqrt(bc2), lr_scale}
+        grp.state16[0] = grp.step
 
     # one eager warm-up step on a side stream (lazy kernel attributes, allocator warm-up), with all training state restored
     saved = [t.clone() for g in (model.grp_G, model.grp_D) for t in (g.flat, g.m, g.v)]
     steps = (model.grp_G.step, model.grp_D.step)
+    pools = (model.pool_B.state_dict(), model.pool_A.state_dict())
     side = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -38,6 +40,7 @@ def _capture(model, real_A, real_B):
         for t in (g.flat, g.m, g.v):
             t.copy_(next(it))
     model.grp_G.step, model.grp_D.step = steps
+    model.pool_B.load_state_dict(pools[0]); model.pool_A.load_state_dict(pools[1])
     model.repack()                                   # the warm-up step left the kernel operands at its own updated weights
 
     st.g1, st.g2, st.g3, st.g4 = (torch.cuda.CUDAGraph() for _ in range(4))
@@ -46,8 +49,12 @@ def _capture(model, real_A, real_B):
         st.fake_B, st.fake_A, lg = model._g_phase(st.xa, st.xb)
         st.lg = torch.cat([l.detach() for l in lg])
     pool = st.g1.pool()
+    # the discriminators read their fakes from static buffers: the image pools (if enabled) fill them between the replays
+    st.pooled = model.pool_B.size > 0
+    st.dfake_B = torch.empty_like(st.fake_B) if st.pooled else st.fake_B
+    st.dfake_A = torch.empty_like(st.fake_A) if st.pooled else st.fake_A
     with torch.cuda.graph(st.g2, pool=pool):
-        ld = model._d_phase(st.xa, st.xb, st.fake_B, st.fake_A)
+        ld = model._d_phase(st.xa, st.xb, st.dfake_B, st.dfake_A)
         st.losses = torch.cat([st.lg, ld[0][0].detach() + ld[0][1].detach(), ld[1][0].detach() + ld[1][1].detach()])
     with torch.cuda.graph(st.g3, pool=pool):
         g = model.grp_G
@@ -83,6 +90,8 @@ def graph_train_step(model, real_A, real_B):
         with torch.cuda.stream(upd):
             model.xchg.wait(h_g, model.device)
             st.g3.replay()
+    if st.pooled:
+        model._pool_fakes(st.fake_B, st.fake_A, st.dfake_B, st.dfake_A)
     st.g2.replay()
     if not model.overlap_update:
         model.xchg.wait(h_g, model.device)
