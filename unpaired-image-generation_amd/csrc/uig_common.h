@@ -83,9 +83,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // stat_out (optional, wave-uniform): fp32[64][2] slot of the InstanceNorm partial-statistics buffer for this wave's 64
 // channels; receives (sum, sum of squares) over the first nvalid pixel rows of the tile AS STORED (rounded to T), so the
 // separate statistics pass of the following InstanceNorm disappears.
-struct NoRowAdd { __device__ __forceinline__ u32x4_t operator()(int, int, const u32x4_t& v) const { return v; } };
-// row_add(r, c, chunk) may modify the 16-byte chunk c of tile row r just before it is stored (border terms of the
-// reflection-pad input gradient).
+struct NoRowAdd { __device__ __forceinline__ u32x4_t operator()(int, int, const u32x4_t& v, int) const { return v; } };
+// row_add(r, c, chunk, i) may modify the 16-byte chunk c of tile row r just before it is stored (border terms of the
+// reflection-pad input gradient); i is the (compile-time, after unrolling) index of the store instruction: r = r0 + RPI*i.
 template <typename T, int MT, int NT, typename RowPtr, typename RowAdd = NoRowAdd>
 __device__ __forceinline__ void store_tile_via_lds(const f32x4_t (&acc)[NT][MT], unsigned char* scratch, int lane,
                                                    const float* bias4 /* NT*4 bias values of this lane, or nullptr */,
@@ -123,7 +123,7 @@ __device__ __forceinline__ void store_tile_via_lds(const f32x4_t (&acc)[NT][MT],
         const int r = r0 + RPI * i;
         T* dst = row_ptr(r);
         const u32x4_t val = *reinterpret_cast<const u32x4_t*>(scratch + r * ROWB + ((c ^ (r & (NCH - 1))) * 16));
-        if (dst != nullptr) *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(dst) + c * 16) = row_add(r, c, val);
+        if (dst != nullptr) *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(dst) + c * 16) = row_add(r, c, val, i);
     }
     if (stat_out != nullptr) {                         // lane <-> channel: column sums over the tile's pixel rows
         const int cb = lane * (int)sizeof(T);          // byte offset of this lane's channel inside an unswizzled row
