@@ -44,7 +44,11 @@ def _capture(model, real_A, real_B):
     model.repack()                                   # the warm-up step left the kernel operands at its own updated weights
 
     st.g1, st.g2, st.g3, st.g4 = (torch.cuda.CUDAGraph() for _ in range(4))
-    with torch.cuda.graph(st.g1):
+    # capture_error_mode thread_local: with a process group alive, RCCL's watchdog thread polls its events (hipEventQuery)
+    # while this thread captures; under the default global mode that poll is an illegal call DURING CAPTURE and aborts the
+    # process (seen in 5 of 8 launches under torchrun).
+    cem = dict(capture_error_mode="thread_local")
+    with torch.cuda.graph(st.g1, **cem):
         st.xa, st.xb = model.to_phys(st.real_A), model.to_phys(st.real_B)
         st.fake_B, st.fake_A, lg = model._g_phase(st.xa, st.xb)
         st.lg = torch.cat([l.detach() for l in lg])
@@ -53,14 +57,14 @@ def _capture(model, real_A, real_B):
     st.pooled = model.pool_B.size > 0
     st.dfake_B = torch.empty_like(st.fake_B) if st.pooled else st.fake_B
     st.dfake_A = torch.empty_like(st.fake_A) if st.pooled else st.fake_A
-    with torch.cuda.graph(st.g2, pool=pool):
+    with torch.cuda.graph(st.g2, pool=pool, **cem):
         ld = model._d_phase(st.xa, st.xb, st.dfake_B, st.dfake_A)
         st.losses = torch.cat([st.lg, ld[0][0].detach() + ld[0][1].detach(), ld[1][0].detach() + ld[1][1].detach()])
-    with torch.cuda.graph(st.g3, pool=pool):
+    with torch.cuda.graph(st.g3, pool=pool, **cem):
         g = model.grp_G
         ops.adam_flat_graph(g.flat, g.grad, g.m, g.v, model.lr, model.b1, model.b2, model.eps, g.state16, 1.0 / model.world)
         model._packer_of("G").run()
-    with torch.cuda.graph(st.g4, pool=pool):
+    with torch.cuda.graph(st.g4, pool=pool, **cem):
         g = model.grp_D
         ops.adam_flat_graph(g.flat, g.grad, g.m, g.v, model.lr, model.b1, model.b2, model.eps, g.state16, 1.0 / model.world)
         model._packer_of("D").run()
