@@ -86,6 +86,34 @@ def test_conv_fwd_bwd(case, dtype):
     assert (db - br.grad).abs().max() <= _tol(dtype, br.grad) * 2
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("S,cin,cout,B,group", [(16, 128, 128, 3, 0), (64, 256, 256, 2, 0), (32, 64, 128, 5, 2), (8, 128, 64, 2, 0)])
+def test_reflect_dgrad_border_paths_agree(S, cin, cout, B, group, dtype):
+    """3x3 reflect-pad input gradient: the in-place ring launch (default) against the padded-gradient + fold path (the plain
+    definition: transposed conv onto the (S+2)x(S+2) grid, mirrored rows / columns folded back) - the same products; only the
+    order of the fp32 / bf16 roundings differs"""
+    u, ops, networks = _mods()
+    torch.manual_seed(5 + S)
+    layer = networks.ConvLayer("conv", cin, cout, 3, 1, 1, "reflect", dtype=dtype, device="cuda"); layer.repack()
+    l2 = networks.ConvLayer("conv", cin, cout, 3, 1, 1, "reflect", dtype=dtype, device="cuda"); l2.repack()
+    dy = (torch.randn(B, S, S, layer.spec.cout_p, device="cuda") * 0.5).to(dtype)
+    pair = (l2.wp_dgrad, None, group) if group else None
+    old = ops.REFLECT_DGRAD_DIRECT
+    try:
+        ops.REFLECT_DGRAD_DIRECT = True
+        a = ops.conv_dgrad(layer.spec, dy, layer.wp_dgrad, (S, S), pair)
+        ops.REFLECT_DGRAD_DIRECT = False
+        b = ops.conv_dgrad(layer.spec, dy, layer.wp_dgrad, (S, S), pair)
+    finally:
+        ops.REFLECT_DGRAD_DIRECT = old
+    torch.cuda.synchronize()
+    scale = float(b.float().abs().max())
+    tol = (2e-5 if dtype == torch.float32 else 1.6e-2) * scale
+    assert float((a.float() - b.float()).abs().max()) <= tol, f"{float((a.float() - b.float()).abs().max())} of {scale}"
+    ring = torch.zeros(S, S, dtype=torch.bool, device="cuda"); ring[1] = ring[S - 2] = True; ring[:, 1] = ring[:, S - 2] = True
+    assert float((a.float() - b.float())[:, ring].abs().max()) <= tol
+
+
 @pytest.mark.parametrize("pm", ["reflect", "zero"])
 def test_wgrad_row_kernel_matches_generic(pm):
     """bf16 ResBlock weight gradient: the image-row kernel (three kw taps per staged row) against the generic split-K kernel
@@ -288,7 +316,7 @@ def test_adam_flat_matches_torch():
     opt = torch.optim.Adam([pr], lr=2e-4, betas=(0.5, 0.999), eps=1e-8)
     p = p0.cuda(); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
     p2 = p0.cuda(); m2 = torch.zeros(n, device="cuda"); v2 = torch.zeros(n, device="cuda")
-    st = torch.zeros(4, dtype=torch.int32, device="cuda")
+    st = ops.new_adam_state("cuda")
     for step in (1, 2, 3, 4):
         g = torch.randn(n) * (10.0 ** (step - 3))
         pr.grad = g.clone(); opt.step()

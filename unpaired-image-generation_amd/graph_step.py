@@ -21,8 +21,7 @@ def _capture(model, real_A, real_B):
     st.real_B = torch.empty_like(real_B, device=dev).copy_(real_B)
     for grp in (model.grp_G, model.grp_D):
         if not hasattr(grp, "state16"):
-            grp.state16 = torch.zeros(4, device=dev, dtype=torch.int32)
-            grp.state16.view(torch.float32)[3] = model.lr_scale      # {step, lr*scale/bc1, 1/sqrt(bc2), lr_scale}
+            grp.state16 = ops.new_adam_state(dev, grp.step, model.lr_scale)
         grp.state16[0] = grp.step
 
     # one eager warm-up step on a side stream (lazy kernel attributes, allocator warm-up), with all training state restored

@@ -601,6 +601,14 @@ def adam_flat(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     L.check(L.lib().uig_adam_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, _stream()), "uig_adam_flat")
 
 
+def new_adam_state(device, step: int = 0, lr_scale: float = 1.0) -> torch.Tensor:
+    """the 16-byte device record of adam_flat_graph: {int step; float lr*scale/bc1; float 1/sqrt(bc2); float lr_scale}"""
+    st = torch.zeros(4, device=device, dtype=torch.int32)
+    st[0] = step
+    st.view(torch.float32)[3] = lr_scale
+    return st
+
+
 def adam_flat_graph(p, g, m, v, lr, beta1, beta2, eps, state16, grad_scale=1.0):
     """Adam whose step counter lives on the device (state16: 4 x int32/float32), so a captured graph can replay it."""
     L.check(L.lib().uig_adam_flat_graph(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, _p(state16), grad_scale, _stream()), "uig_adam_flat_graph")
