@@ -109,6 +109,11 @@ int uig_wgrad_pair_splits(int B, int group_images, int Mh, int Mw, int Np, int H
 int uig_wgrad_partial_pair(const void* P, const void* Q, float* workspace, int B, int group_images, int Mh, int Mw,
                            int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int pad_mode,
                            int splits, int dtype, void* stream);
+/* both halves of a uig_wgrad_partial_pair workspace in one launch (colsum_* NULL = no bias gradient on this launch) */
+int uig_wgrad_reduce_pair(const float* workspace, float* dW_a, float* dW_b, int Np, int Cq, int taps, int splits,
+                          int D0, int D1, int accumulate, const float* colsum_a, const float* colsum_b,
+                          int nslab_a, int nslab_b, int C, int Nreal, float* db_a, float* db_b, int accumulate_db,
+                          void* stream);
 int uig_wgrad_reduce(const float* workspace, float* dW, int Np, int Cq, int taps, int splits,
                      int D0, int D1, int accumulate, void* stream);
 /* uig_wgrad_reduce + the layer's bias gradient from the InstanceNorm backward's column-sum partials, in one launch */

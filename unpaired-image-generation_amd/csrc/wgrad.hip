@@ -258,10 +258,12 @@ __device__ __forceinline__ void bias_rider_block(const BiasRider& br, int blk) {
 // one-thread-per-element form wrote with a stride of `taps` floats and ran at 1.6 TB/s).
 template <int TAPS>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int Np, int Cq,
-                                                            int taps_rt, int splits, int D0, int D1, int accumulate, const BiasRider br) {
-    if ((int)blockIdx.x >= br.main_blocks) { bias_rider_block(br, blockIdx.x - br.main_blocks); return; }
+                                                            int taps_rt, int splits, int D0, int D1, int accumulate, BiasRider br,
+                                                            float* __restrict__ dW2, const BiasRider br2) {
     const int taps = TAPS > 0 ? TAPS : taps_rt;
     const long slab = (long)Np * taps * Cq;
+    if (blockIdx.y) { part += (long)splits * slab; dW = dW2; br = br2; }      // second network of a paired launch
+    if ((int)blockIdx.x >= br.main_blocks) { if (br.cpart) bias_rider_block(br, blockIdx.x - br.main_blocks); return; }
     const int total = D0 * D1;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += br.main_blocks * blockDim.x) {
         const int d1 = i % D1, d0 = i / D1;
@@ -290,10 +292,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // few (d0, d1) pairs (3-channel stem / head, 1-channel discriminator head): 16 output ELEMENTS per block, 16 split lanes per
 // element (these layers run with up to 512 splits; one thread per element walked them serially: 100+ us)
 __global__ __launch_bounds__(256) void wgrad_reduce_elem_kernel(const float* __restrict__ part, float* __restrict__ dW, int Np, int Cq, int taps,
-                                                                 int splits, int D0, int D1, int accumulate, const BiasRider br) {
-    if ((int)blockIdx.x >= br.main_blocks) { bias_rider_block(br, blockIdx.x - br.main_blocks); return; }
+                                                                 int splits, int D0, int D1, int accumulate, BiasRider br,
+                                                                 float* __restrict__ dW2, const BiasRider br2) {
     const long total = (long)D0 * D1 * taps;
     const long slab = (long)Np * taps * Cq;
+    if (blockIdx.y) { part += (long)splits * slab; dW = dW2; br = br2; }      // second network of a paired launch
+    if ((int)blockIdx.x >= br.main_blocks) { if (br.cpart) bias_rider_block(br, blockIdx.x - br.main_blocks); return; }
     const int sl = threadIdx.x & 15;
     for (long i = (long)blockIdx.x * 16 + (threadIdx.x >> 4); i < total + 15; i += (long)br.main_blocks * 16) {   // uniform trip count per 16-lane group
         const bool ok = i < total;
@@ -441,25 +445,43 @@ extern "C" int uig_wgrad_partial_pair(const void* P, const void* Q, float* works
 }
 
 static int wgrad_reduce_impl(const float* workspace, float* dW, int Np, int Cq, int taps, int splits, int D0, int D1, int accumulate,
-                             BiasRider br, void* stream) {
+                             BiasRider br, void* stream, float* dW2 = nullptr, BiasRider br2 = BiasRider{nullptr, nullptr, 0, 0, 0, 0, 0}) {
     UIG_CHECK_ARG(workspace && dW, "uig_wgrad_reduce: null pointer");
     UIG_CHECK_ARG(D0 <= Np && D1 <= Cq && D0 > 0 && D1 > 0 && taps > 0 && splits > 0, "uig_wgrad_reduce: bad dims");
     const long total = (long)D0 * D1;
     hipStream_t s = (hipStream_t)stream;
-    const int extra = br.cpart ? (br.C + 15) / 16 : 0;
+    const int extra = (br.cpart || br2.cpart) ? (std::max(br.C, br2.C) + 15) / 16 : 0;
+    const int ny = dW2 ? 2 : 1;                        // paired launch: blockIdx.y = network
     if (total < 8192) {
         const long tot_e = total * taps;
-        br.main_blocks = (int)std::max<long>(1, std::min<long>((tot_e + 15) / 16, 4096));
-        hipLaunchKernelGGL(wgrad_reduce_elem_kernel, dim3(br.main_blocks + extra), dim3(256), 0, s, workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate, br);
+        br.main_blocks = br2.main_blocks = (int)std::max<long>(1, std::min<long>((tot_e + 15) / 16, 4096));
+        hipLaunchKernelGGL(wgrad_reduce_elem_kernel, dim3(br.main_blocks + extra, ny), dim3(256), 0, s, workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate, br, dW2, br2);
     } else {
-        br.main_blocks = (int)std::max<long>(1, std::min<long>((total + 255) / 256, 4096));
-        const dim3 g(br.main_blocks + extra);
-        if (taps == 9) hipLaunchKernelGGL(wgrad_reduce_kernel<9>, g, dim3(256), 0, s, workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate, br);
-        else if (taps == 16) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, g, dim3(256), 0, s, workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate, br);
-        else hipLaunchKernelGGL(wgrad_reduce_kernel<0>, g, dim3(256), 0, s, workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate, br);
+        br.main_blocks = br2.main_blocks = (int)std::max<long>(1, std::min<long>((total + 255) / 256, 4096));
+        const dim3 g(br.main_blocks + extra, ny);
+        if (taps == 9) hipLaunchKernelGGL(wgrad_reduce_kernel<9>, g, dim3(256), 0, s, workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate, br, dW2, br2);
+        else if (taps == 16) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, g, dim3(256), 0, s, workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate, br, dW2, br2);
+        else hipLaunchKernelGGL(wgrad_reduce_kernel<0>, g, dim3(256), 0, s, workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate, br, dW2, br2);
     }
     UIG_LAUNCH_CHECK("uig_wgrad_reduce");
     return 0;
+}
+
+// Both halves of a uig_wgrad_partial_pair workspace in ONE launch: network a -> dW_a (+ optional bias rider a), network b ->
+// dW_b.  colsum_* may be NULL (no bias gradient on this launch).
+extern "C" int uig_wgrad_reduce_pair(const float* workspace, float* dW_a, float* dW_b, int Np, int Cq, int taps, int splits,
+                                     int D0, int D1, int accumulate, const float* colsum_a, const float* colsum_b,
+                                     int nslab_a, int nslab_b, int C, int Nreal, float* db_a, float* db_b, int accumulate_db,
+                                     void* stream) {
+    UIG_CHECK_ARG(dW_a && dW_b, "uig_wgrad_reduce_pair: null pointer");
+    UIG_CHECK_ARG((colsum_a == nullptr) == (colsum_b == nullptr), "uig_wgrad_reduce_pair: bias riders for both networks or for none");
+    BiasRider ra{nullptr, nullptr, 0, 0, 0, 0, 0}, rb = ra;
+    if (colsum_a != nullptr) {
+        UIG_CHECK_ARG(db_a && db_b && nslab_a > 0 && nslab_b > 0 && Nreal > 0 && Nreal <= C, "uig_wgrad_reduce_pair: bad bias args");
+        ra = BiasRider{colsum_a, db_a, nslab_a, C, Nreal, accumulate_db, 0};
+        rb = BiasRider{colsum_b, db_b, nslab_b, C, Nreal, accumulate_db, 0};
+    }
+    return wgrad_reduce_impl(workspace, dW_a, Np, Cq, taps, splits, D0, D1, accumulate, ra, stream, dW_b, rb);
 }
 
 extern "C" int uig_wgrad_reduce(const float* workspace, float* dW, int Np, int Cq, int taps, int splits,

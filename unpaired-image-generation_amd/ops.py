@@ -407,6 +407,35 @@ def _param_grads(layer, spec, x, dy, need_w, need_b, colsum=None, img0=0, partia
     return dW, db
 
 
+def _param_grads_pair(layers, spec, x, dy, group, colsum, pparts):
+    """Both networks' dW (+ db) from a paired partial workspace in ONE reduce launch.  Only the training configuration
+    (gradients accumulated in place into existing contiguous .grad buffers of both layers); returns False otherwise."""
+    l1, l2 = layers
+    for l in layers:
+        if not (l.fuse_grad_accum and l.weight.grad is not None and l.weight.grad.is_contiguous()
+                and l.bias.grad is not None and l.bias.grad.is_contiguous()):
+            return False
+    (ws1, splits), (ws2, _) = pparts
+    if ws2.data_ptr() != ws1.data_ptr() + ws1.numel() * 4:
+        return False
+    k = spec.k
+    _, _, _, _, Np, _, _, Cq, _, D0, D1 = _wgrad_operands(spec, x, dy)
+    rider = colsum is not None and colsum[2] == dy.shape[3]
+    lib = L.lib()
+    if rider:
+        cpart, spi, C = colsum
+        ca, cb = cpart, cpart[group * spi * C * 2:]
+        L.check(lib.uig_wgrad_reduce_pair(_p(ws1), _p(l1.weight.grad), _p(l2.weight.grad), Np, Cq, k * k, splits, D0, D1, 1, _p(ca), _p(cb),
+                                          group * spi, (dy.shape[0] - group) * spi, C, spec.cout, _p(l1.bias.grad), _p(l2.bias.grad), 1,
+                                          _stream()), "uig_wgrad_reduce_pair")
+    else:
+        L.check(lib.uig_wgrad_reduce_pair(_p(ws1), _p(l1.weight.grad), _p(l2.weight.grad), Np, Cq, k * k, splits, D0, D1, 1, None, None,
+                                          0, 0, 0, 0, None, None, 0, _stream()), "uig_wgrad_reduce_pair")
+        for l, dys in ((l1, dy[:group]), (l2, dy[group:])):
+            bias_grad(dys, spec.cout, out=l.bias.grad, accumulate=True)
+    return True
+
+
 def _conv_backward(ctx, dy, layers, group):
     """Shared backward of ConvFn / PairConvFn.  The input gradient and the parameter gradients are independent given dy:
     the parameter-gradient kernels are forked onto a side stream and joined before returning.  The input-gradient grid
@@ -442,7 +471,11 @@ def _conv_backward(ctx, dy, layers, group):
         side.wait_stream(main)
     with (torch.cuda.stream(side) if par else contextlib.nullcontext()):
         pparts = conv_wgrad_pair_partial(spec, x, dy, group) if (npar == 2 and all(need_w) and PAIR_WGRAD) else None
-        for i, layer in enumerate(layers):
+        if pparts and all(need_b) and _param_grads_pair(layers, spec, x, dy, group, colsum, pparts):
+            grads, layers_left = [None] * (2 * npar), ()
+        else:
+            layers_left = layers
+        for i, layer in enumerate(layers_left):
             if npar == 1:
                 xs, dys, i0 = x, dy, 0
             else:
