@@ -109,11 +109,16 @@ class CycleGAN:
         self.grp_D.set_requires_grad(False)
         self.grp_G.zero_grad()
         if self.batch_fused and self.paired:
-            # G_A on [xa; xb] and G_B on [xb; xa] as ONE paired pass over 4B images, then G_B(fake_B) / G_A(fake_A) as one
-            o = pair_forward_phys(self.G_A, self.G_B, torch.cat([xa, xb, xb, xa]))
-            fake_B, idt_A, fake_A, idt_B = o[:B], o[B:2 * B], o[2 * B:3 * B], o[3 * B:]
-            r = pair_forward_phys(self.G_B, self.G_A, torch.cat([fake_B, fake_A]))
-            rec_A, rec_B = r[:B], r[B:]
+            # G_A on [xb; xa] and G_B on [xb; xa] as ONE paired pass over 4B images -> [idt_A, fake_B | fake_A, idt_B]: the two
+            # fakes are adjacent, so the batch [fake_B; fake_A] that feeds both the cycle pass and the discriminators is a view
+            # of the output (no concatenation), and torch.split keeps the backward at ONE concatenation of the three gradient
+            # pieces (slicing o four times cost four zero-filled full-size gradients and three adds per step).
+            x2 = torch.cat([xb, xa])
+            o = pair_forward_phys(self.G_A, self.G_B, torch.cat([x2, x2]))
+            idt_A, ff, idt_B = torch.split(o, [B, 2 * B, B])
+            fake_B, fake_A = ff[:B], ff[B:]
+            r = pair_forward_phys(self.G_B, self.G_A, ff)          # G_B(fake_B) = rec_A ; G_A(fake_A) = rec_B
+            rec_A, rec_B = torch.split(r, B)
         elif self.batch_fused:
             oa = self.G_A.forward_phys(torch.cat([xa, xb]))      # [fake_B ; idt_A]
             ob = self.G_B.forward_phys(torch.cat([xb, xa]))      # [fake_A ; idt_B]
@@ -127,8 +132,8 @@ class CycleGAN:
         l_idt_A = ops.l1_loss(idt_A, xb, self.lam * self.lam_idt, n_real)
         l_idt_B = ops.l1_loss(idt_B, xa, self.lam * self.lam_idt, n_real)
         if self.batch_fused and self.paired:
-            pd = pair_forward_phys(self.D_A, self.D_B, torch.cat([fake_B, fake_A]))
-            l_G_A, l_G_B = ops.mse_const(pd[:B], 1.0), ops.mse_const(pd[B:], 1.0)
+            pd_A, pd_B = torch.split(pair_forward_phys(self.D_A, self.D_B, ff), B)
+            l_G_A, l_G_B = ops.mse_const(pd_A, 1.0), ops.mse_const(pd_B, 1.0)
         else:
             l_G_A = ops.mse_const(self.D_A.forward_phys(fake_B), 1.0)
             l_G_B = ops.mse_const(self.D_B.forward_phys(fake_A), 1.0)
@@ -146,9 +151,9 @@ class CycleGAN:
         B = xa.shape[0]
         out = []
         if self.batch_fused and self.paired:      # D_A on [real_B; fake_B] and D_B on [real_A; fake_A] as one paired pass
-            p = pair_forward_phys(self.D_A, self.D_B, torch.cat([xb, fake_B, xa, fake_A]))
-            ls = [ops.mse_const(p[:B], 1.0, 0.5), ops.mse_const(p[B:2 * B], 0.0, 0.5),
-                  ops.mse_const(p[2 * B:3 * B], 1.0, 0.5), ops.mse_const(p[3 * B:], 0.0, 0.5)]
+            p = torch.split(pair_forward_phys(self.D_A, self.D_B, torch.cat([xb, fake_B, xa, fake_A])), B)
+            ls = [ops.mse_const(p[0], 1.0, 0.5), ops.mse_const(p[1], 0.0, 0.5),
+                  ops.mse_const(p[2], 1.0, 0.5), ops.mse_const(p[3], 0.0, 0.5)]
             with ops.deferred_param_grads(self.device) if self.defer_join else contextlib.nullcontext():
                 torch.autograd.backward(ls)
             return [(ls[0], ls[1]), (ls[2], ls[3])]
