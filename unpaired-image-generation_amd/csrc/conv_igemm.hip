@@ -349,6 +349,16 @@ static int dispatch_igemm(const void* x, const void* wp, const float* bias, void
     }
     // Measured on MI355X (ResBlock conv, batch 8): 128x128 / 4 waves / 2 blocks per CU = 701 TF, 128x256 / 8 waves / 3-stage
     // ring = 683 TF (both limited by the per-CU L2->LDS path), so the narrow tile stays the default.
+    // Few 128x128 tiles (< 1.5 per CU) with a long reduction (the PatchGAN's 4x4 256->512 layer: 256 tiles x 128 K-steps) run one
+    // latency-bound block per CU; half-width tiles double the blocks so that two co-resident blocks cover each other's
+    // waits.  Not with fused InstanceNorm statistics (those need the 64x64 wave tile's LDS epilogue).
+    {
+        const long mt = ((long)d.B * d.Mh * d.Mw + 127) / 128;
+        const long tiles = mt * ((d.Nrows + 127) / 128) * d.nphase;
+        const int ksteps = (d.ph_tap0[1] - d.ph_tap0[0]) * (d.Cin / BK);
+        if (!small && d.in_partial == nullptr && (g_force_tile == 64 || (g_force_tile == 0 && tiles < 384 && ksteps >= 32 && d.nphase == 1)))
+            return launch_igemm<T, 128, 64, 2, 2, 2, false>(x, wp, bias, y, d, s);
+    }
     const bool wide = g_force_tile == 256;
     if (wide)      // full-width tile: the im2col tile is staged once per pixel tile, 8 waves, 3-stage DMA ring
         return small ? launch_igemm<T, 128, 256, 2, 4, 3, true>(x, wp, bias, y, d, s)
