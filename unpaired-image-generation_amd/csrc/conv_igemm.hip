@@ -83,13 +83,17 @@ void igemm_kernel(const T* __restrict__ x, const T* __restrict__ wp_, const floa
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (o >> 3);
     }
     const int ntn = (d.Nrows + BN - 1) / BN;
-    const int n_base = (bid % ntn) * BN, m_base = (bid / ntn) * BM;
-    const bool g2 = d.wp2 != nullptr && m_base >= d.group_rows;        // block-uniform: tiles never straddle the groups
+    // paired launch: each network's rows get their own run of tiles (group 1 starts at row group_rows whatever its alignment),
+    // so a block never straddles the two weight sets; rows past the end of a group are masked like the ragged last tile
+    const int mtile = bid / ntn;
+    const int gt0 = d.wp2 != nullptr ? (d.group_rows + BM - 1) / BM : 0;
+    const bool g2 = d.wp2 != nullptr && mtile >= gt0;
+    const int n_base = (bid % ntn) * BN, m_base = g2 ? d.group_rows + (mtile - gt0) * BM : mtile * BM;
     const T* wp = g2 ? static_cast<const T*>(d.wp2) : wp_;
     const float* bias = g2 ? d.bias2 : bias_;
     const int ph = blockIdx.y;
     const int tap0 = d.ph_tap0[ph], ntap = d.ph_tap0[ph + 1] - tap0;
-    const int M = d.B * d.Mh * d.Mw;
+    const int M = (d.wp2 != nullptr && !g2) ? d.group_rows : d.B * d.Mh * d.Mw;      // end of this block's group
     const int Cin = d.Cin;
 
     // ---- per-thread row bookkeeping for the gather
@@ -318,7 +322,8 @@ UIG_INST(float, 256, 16, 4, 1, 2) UIG_INST(float, 128, 64, 2, 2, 2) UIG_INST(flo
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, bool SMALL>
 static int launch_igemm(const void* x, const void* wp, const float* bias, void* y, const GatherDesc& d, hipStream_t s) {
     const int M = d.B * d.Mh * d.Mw;
-    const int mt = (M + BM - 1) / BM, nt = (d.Nrows + BN - 1) / BN;
+    const int mt = d.wp2 != nullptr ? (d.group_rows + BM - 1) / BM + (M - d.group_rows + BM - 1) / BM : (M + BM - 1) / BM;
+    const int nt = (d.Nrows + BN - 1) / BN;
     const size_t smem = NSTAGE * (size_t)(BM + BN) * 128;
     auto kern = igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, NSTAGE, SMALL>;
     static bool attr_done = false;   // benign race: idempotent
@@ -475,7 +480,7 @@ static int conv_gather_impl(const void* x, const void* wp, const float* bias, co
     UIG_CHECK_ARG(border_add == nullptr, "uig_conv_gather_ex: border_add needs the stride-1 3x3 strip kernel (query uig_conv_strip_applicable)");
     if (wp2 != nullptr) {
         const long grows = (long)group_images * d.Mh * d.Mw;
-        if (grows % 256 != 0) {      // a tile could straddle the two groups: run them as two launches (same results)
+        if (grows % 256 != 0 && in_partial != nullptr) {      // fused-statistics slabs assume 64-row alignment of both groups: two launches (same results)
             const long esz2 = dtype == UIG_BF16 ? 2 : 4;
             const long pstride = (long)(Ho * Wo / 64) * Nstore * 2;
             int rc = conv_gather_impl(x, wp, bias, nullptr, nullptr, 0, in_partial, nullptr, y, group_images, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode,
