@@ -68,9 +68,11 @@ int uig_conv_gather_pair(const void* x, const void* wp, const float* bias, const
  * (fp32[B * (Ho*Wo/64) * Nstore * 2]) receives per-64-pixel (sum, sum of squares) of the stored output per channel, consumed by
  * uig_instnorm_act_fwd_pre.  Needs Nrows a multiple of 64 (> 64), Nstore == Nrows and (gather grid) % 64 == 0.
  * border_add (optional, strip kernel only: uig_conv_strip_applicable): the compact border buffer of
- * uig_reflect3x3_dgrad_border, added to output rows 1 / H-2 and columns 1 / W-2 in the epilogue. */
+ * uig_reflect3x3_dgrad_border, added to output rows 1 / H-2 and columns 1 / W-2 in the epilogue.
+ * res_add (optional, strip kernel only): a tensor of y's shape and dtype added to the output in the epilogue (the ResBlock's
+ * skip gradient in the input-gradient launch: saves the separate gradient-accumulation pass). */
 int uig_conv_gather_ex(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2,
-                       int group_images, float* in_partial, const void* border_add, void* y,
+                       int group_images, float* in_partial, const void* border_add, const void* res_add, void* y,
                        int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
                        int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
                        int act, float slope, int dtype, void* stream);

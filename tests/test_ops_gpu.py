@@ -114,6 +114,42 @@ def test_reflect_dgrad_border_paths_agree(S, cin, cout, B, group, dtype):
     assert float((a.float() - b.float())[:, ring].abs().max()) <= tol
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("S", [16, 64, 20])
+def test_resblock_skip_gradient_fusion(S, dtype):
+    """ResBlock backward: the skip path's gradient summed into the first conv's input-gradient launch (ops.SkipLink) against
+    autograd's own accumulation (separate add): same sums, one rounding fewer.  S = 20 is a map the strip kernel's border
+    path does not take on this layer... the fallback (in-place add) must give the same result."""
+    u, ops, networks = _mods()
+    torch.manual_seed(40 + S)
+    blk = networks.ResBlock(128, dtype, "cuda")
+    for l in blk.b:
+        if hasattr(l, "repack"):
+            l.repack()
+    x0 = (torch.randn(3, S, S, 128, device="cuda")).to(dtype)
+    dy = (torch.randn(3, S, S, 128, device="cuda") * 0.5).to(dtype)
+    res = []
+    old = ops.FUSE_SKIP_GRAD
+    try:
+        for flag in (True, False):
+            ops.FUSE_SKIP_GRAD = flag
+            x = x0.clone().requires_grad_(True)
+            z = (x * 1.0)                       # non-leaf input, as inside a generator
+            y = blk(z)
+            y.backward(dy)
+            res.append((x.grad.clone(), [p.grad.clone() for p in blk.parameters()]))
+            for p in blk.parameters():
+                p.grad = None
+    finally:
+        ops.FUSE_SKIP_GRAD = old
+    (ga, pa), (gb, pb) = res
+    scale = float(gb.float().abs().max())
+    tol = (2e-5 if dtype == torch.float32 else 1.6e-2) * scale
+    assert float((ga.float() - gb.float()).abs().max()) <= tol
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)                # parameter gradients do not depend on where the sum happens
+
+
 @pytest.mark.parametrize("pm", ["reflect", "zero"])
 def test_wgrad_row_kernel_matches_generic(pm):
     """bf16 ResBlock weight gradient: the image-row kernel (three kw taps per staged row) against the generic split-K kernel

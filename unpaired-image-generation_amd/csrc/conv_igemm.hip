@@ -377,7 +377,7 @@ static int dispatch_igemm(const void* x, const void* wp, const float* bias, void
 }
 
 int uig_try_conv_strip(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
-                       float* in_partial, const void* border_add, void* y, int B, int H, int W, int Cin, int Nrows,
+                       float* in_partial, const void* border_add, const void* res_add, void* y, int B, int H, int W, int Cin, int Nrows,
                        int k, int pad_mode, const int* taps, int ntaps, int dh_min, int dh_max, int Ho, int Wo, int ldc, int Nstore,
                        int act, float slope, int dtype, long x_bytes, long w_bytes, hipStream_t s, int* rc_out);
 
@@ -392,7 +392,7 @@ int uig_try_conv_rowstrip(const void* x, const void* wp, const float* bias, cons
 static int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
 static int conv_gather_impl(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
-                            float* in_partial, const void* border_add, void* y, int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
+                            float* in_partial, const void* border_add, const void* res_add, void* y, int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
                             int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
                             int act, float slope, int dtype, void* stream) {
     UIG_CHECK_ARG(x && wp && y, "uig_conv_gather: null pointer");
@@ -458,13 +458,13 @@ static int conv_gather_impl(const void* x, const void* wp, const float* bias, co
         d.in_partial = in_partial;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (gather_mode == UIG_GATHER_DIRECT && in_partial == nullptr && border_add == nullptr) {   // 1..4 output channels, wide input: one wave per dot product
+    if (gather_mode == UIG_GATHER_DIRECT && in_partial == nullptr && border_add == nullptr && res_add == nullptr) {   // 1..4 output channels, wide input: one wave per dot product
         int rc = 0;
         if (uig_try_conv_gemv(x, wp, bias, wp2, bias2, group_images, y, B, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode, Ho, Wo, ldc, Nstore,
                               act, slope, dtype, s, &rc))
             return rc;
     }
-    if (d.nphase == 1 && stride == 1 && kH == kW && in_partial == nullptr && border_add == nullptr) {   // few output channels, many taps
+    if (d.nphase == 1 && stride == 1 && kH == kW && in_partial == nullptr && border_add == nullptr && res_add == nullptr) {   // few output channels, many taps
         int rc = 0;
         if (uig_try_conv_rowstrip(x, wp, bias, wp2, bias2, group_images, y, B, H, W, Cin, Nrows, kH, pad_mode, d.tap, kH * kW, Ho, Wo,
                                   ldc, Nstore, act, slope, dtype, (long)d.x_bytes, (long)d.w_bytes, s, &rc))
@@ -473,21 +473,21 @@ static int conv_gather_impl(const void* x, const void* wp, const float* bias, co
     if (d.nphase == 1 && stride == 1 && kH == kW) {      // stride-1 k x k: LDS-resident input strip kernel (conv_strip.hip)
         int dmin = 127, dmax = -127, rc = 0;
         for (int t = 0; t < kH * kW; ++t) { const int dh = (d.tap[t] & 255) - 128; dmin = std::min(dmin, dh); dmax = std::max(dmax, dh); }
-        if (uig_try_conv_strip(x, wp, bias, wp2, bias2, group_images, in_partial, border_add, y, B, H, W, Cin, Nrows, kH, pad_mode, d.tap, kH * kW, dmin, dmax,
+        if (uig_try_conv_strip(x, wp, bias, wp2, bias2, group_images, in_partial, border_add, res_add, y, B, H, W, Cin, Nrows, kH, pad_mode, d.tap, kH * kW, dmin, dmax,
                                Ho, Wo, ldc, Nstore, act, slope, dtype, (long)d.x_bytes, (long)d.w_bytes, s, &rc))
             return rc;
     }
-    UIG_CHECK_ARG(border_add == nullptr, "uig_conv_gather_ex: border_add needs the stride-1 3x3 strip kernel (query uig_conv_strip_applicable)");
+    UIG_CHECK_ARG(border_add == nullptr && res_add == nullptr, "uig_conv_gather_ex: border_add / res_add need the stride-1 3x3 strip kernel (query uig_conv_strip_applicable)");
     if (wp2 != nullptr) {
         const long grows = (long)group_images * d.Mh * d.Mw;
         if (grows % 256 != 0 && in_partial != nullptr) {      // fused-statistics slabs assume 64-row alignment of both groups: two launches (same results)
             const long esz2 = dtype == UIG_BF16 ? 2 : 4;
             const long pstride = (long)(Ho * Wo / 64) * Nstore * 2;
-            int rc = conv_gather_impl(x, wp, bias, nullptr, nullptr, 0, in_partial, nullptr, y, group_images, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode,
+            int rc = conv_gather_impl(x, wp, bias, nullptr, nullptr, 0, in_partial, nullptr, nullptr, y, group_images, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode,
                                       gather_mode, Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
             if (rc) return rc;
             return conv_gather_impl((const char*)x + (long)group_images * H * W * Cin * esz2, wp2, bias2, nullptr, nullptr, 0,
-                                    in_partial ? in_partial + group_images * pstride : nullptr, nullptr, (char*)y + (long)group_images * Ho * Wo * ldc * esz2, B - group_images, H, W, Cin, Nrows, kH, kW,
+                                    in_partial ? in_partial + group_images * pstride : nullptr, nullptr, nullptr, (char*)y + (long)group_images * Ho * Wo * ldc * esz2, B - group_images, H, W, Cin, Nrows, kH, kW,
                                     stride, pad, pad_mode, gather_mode, Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
         }
         d.wp2 = wp2; d.bias2 = bias2; d.group_rows = (int)grows;
@@ -499,7 +499,7 @@ extern "C" int uig_conv_gather(const void* x, const void* wp, const float* bias,
                                int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
                                int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
                                int act, float slope, int dtype, void* stream) {
-    return conv_gather_impl(x, wp, bias, nullptr, nullptr, 0, nullptr, nullptr, y, B, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode, gather_mode,
+    return conv_gather_impl(x, wp, bias, nullptr, nullptr, 0, nullptr, nullptr, nullptr, y, B, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode, gather_mode,
                             Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
 }
 
@@ -509,16 +509,16 @@ extern "C" int uig_conv_gather_pair(const void* x, const void* wp, const float* 
                                     int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
                                     int act, float slope, int dtype, void* stream) {
     UIG_CHECK_ARG(wp2 != nullptr, "uig_conv_gather_pair: null wp2");
-    return conv_gather_impl(x, wp, bias, wp2, bias2, group_images, nullptr, nullptr, y, B, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode, gather_mode,
+    return conv_gather_impl(x, wp, bias, wp2, bias2, group_images, nullptr, nullptr, nullptr, y, B, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode, gather_mode,
                             Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
 }
 
 extern "C" int uig_conv_gather_ex(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2,
-                                  int group_images, float* in_partial, const void* border_add, void* y,
+                                  int group_images, float* in_partial, const void* border_add, const void* res_add, void* y,
                                   int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
                                   int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
                                   int act, float slope, int dtype, void* stream) {
-    return conv_gather_impl(x, wp, bias, wp2, bias2, wp2 ? group_images : 0, in_partial, border_add, y, B, H, W, Cin, Nrows, kH, kW, stride, pad,
+    return conv_gather_impl(x, wp, bias, wp2, bias2, wp2 ? group_images : 0, in_partial, border_add, res_add, y, B, H, W, Cin, Nrows, kH, kW, stride, pad,
                             pad_mode, gather_mode, Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
 }
 

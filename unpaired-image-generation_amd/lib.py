@@ -28,7 +28,7 @@ SIGNATURES = {
     "uig_debug_set_strip_stamps": (None, [_vp]),
     "uig_conv_gather": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_i, _f, _i, _vp]),
     "uig_conv_gather_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp] + [_i] * 15 + [_i, _f, _i, _vp]),
-    "uig_conv_gather_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp] + [_i] * 15 + [_i, _f, _i, _vp]),
+    "uig_conv_gather_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp] + [_i] * 15 + [_i, _f, _i, _vp]),
     "uig_reflect3x3_dgrad_border": (_i, [_vp, _vp, _vp, _i, _vp] + [_i] * 7 + [_vp]),
     "uig_conv_strip_applicable": (_i, [_i] * 10),
     "uig_wgrad_workspace_bytes": (_sz, [_i] * 5),

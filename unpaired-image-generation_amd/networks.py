@@ -56,9 +56,9 @@ class ConvLayer(nn.Module):
         if self._packed_version != self.weight._version:
             self.repack()
 
-    def forward(self, x):
+    def forward(self, x, skip_link=None):
         self.ensure_packed()
-        return ops.ConvFn.apply(x, self.weight, self.bias, self)
+        return ops.ConvFn.apply(x, self.weight, self.bias, self, skip_link)
 
     def extra_repr(self):
         s = self.spec
@@ -72,8 +72,8 @@ class InstNormAct(nn.Module):
         super().__init__()
         self.act, self.slope, self.eps = act, slope, eps
 
-    def forward(self, x, residual=None):
-        return ops.InstNormActFn.apply(x, residual, self.act, self.slope, self.eps)
+    def forward(self, x, residual=None, skip_link=None):
+        return ops.InstNormActFn.apply(x, residual, self.act, self.slope, self.eps, skip_link)
 
 
 class ResBlock(nn.Module):
@@ -92,8 +92,10 @@ class ResBlock(nn.Module):
         )
 
     def forward(self, x):
-        h = self.b[2](self.b[1](x))
-        return self.b[6](self.b[5](h), residual=x)
+        # the skip path's gradient is summed into the first conv's input-gradient launch (ops.SkipLink), not by autograd
+        link = ops.SkipLink() if (x.requires_grad and torch.is_grad_enabled()) else None
+        h = self.b[2](self.b[1](x, skip_link=link))
+        return self.b[6](self.b[5](h), residual=x, skip_link=link)
 
 
 class _PhysNet(nn.Sequential):
@@ -180,18 +182,19 @@ def pair_forward_phys(net1: _PhysNet, net2: _PhysNet, x: torch.Tensor) -> torch.
         raise ValueError("pair_forward_phys: the stacked batch must be even")
     g = x.shape[0] // 2
 
-    def conv(l1, l2, t):
+    def conv(l1, l2, t, link=None):
         if l1.spec.__dict__ != l2.spec.__dict__:
             raise ValueError("pair_forward_phys: the two networks differ")
         l1.ensure_packed(); l2.ensure_packed()
-        return ops.PairConvFn.apply(t, l1.weight, l1.bias, l2.weight, l2.bias, l1, l2, g)
+        return ops.PairConvFn.apply(t, l1.weight, l1.bias, l2.weight, l2.bias, l1, l2, g, link)
 
     for m1, m2 in zip(net1, net2):
         if isinstance(m1, ConvLayer):
             x = conv(m1, m2, x)
         elif isinstance(m1, ResBlock):
-            h = m1.b[2](conv(m1.b[1], m2.b[1], x))
-            x = m1.b[6](conv(m1.b[5], m2.b[5], h), residual=x)
+            link = ops.SkipLink() if (x.requires_grad and torch.is_grad_enabled()) else None
+            h = m1.b[2](conv(m1.b[1], m2.b[1], x, link))
+            x = m1.b[6](conv(m1.b[5], m2.b[5], h), residual=x, skip_link=link)
         else:                      # InstNormAct / _Slot: no parameters, per-sample
             x = m1(x)
     return x

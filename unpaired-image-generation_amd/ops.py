@@ -18,6 +18,7 @@ from . import lib as L
 
 REFLECT_DGRAD_DIRECT = os.environ.get("UIG_REFLECT_DGRAD_DIRECT", "1") != "0"   # 3x3 reflect-pad convs: input gradient on the exact grid + border GEMM (no padded gradient, no fold)
 PAIR_WGRAD = os.environ.get("UIG_PAIR_WGRAD", "1") != "0"                   # paired layers: both networks' weight-gradient partials in one launch where the library supports it
+FUSE_SKIP_GRAD = os.environ.get("UIG_FUSE_SKIP_GRAD", "1") != "0"           # ResBlock: the skip path's gradient is added in conv1's input-gradient epilogue instead of by a separate add kernel
 PARALLEL_BACKWARD = os.environ.get("UIG_PARALLEL_BACKWARD", "1") != "0"      # run a conv's parameter-gradient kernels concurrently with its input-gradient kernel
 _SIDE_STREAMS = {}
 _DEFER_JOIN = {}
@@ -206,13 +207,13 @@ def packed_shapes(spec: ConvSpec):
 
 
 def _gather(x, wp, bias, y, B, H, W, C, nrows, spec, stride, pad, pm, mode, Ho, Wo, ldc, act, slope, what, pair=None,
-            in_partial=None, border_add=None):
+            in_partial=None, border_add=None, res_add=None):
     """one uig_conv_gather launch; pair = (wp2, bias2, group_images) makes it a two-network launch; in_partial receives the
-    fused InstanceNorm statistics partials"""
+    fused InstanceNorm statistics partials; res_add (a tensor of y's shape) is added to the output in the epilogue"""
     lib = L.lib()
-    if in_partial is not None or border_add is not None:
+    if in_partial is not None or border_add is not None or res_add is not None:
         wp2, bias2, g = pair if pair is not None else (None, None, 0)
-        rc = lib.uig_conv_gather_ex(_p(x), _p(wp), _p(bias), _p(wp2), _p(bias2), g, _p(in_partial), _p(border_add), _p(y), B, H, W, C, nrows,
+        rc = lib.uig_conv_gather_ex(_p(x), _p(wp), _p(bias), _p(wp2), _p(bias2), g, _p(in_partial), _p(border_add), _p(res_add), _p(y), B, H, W, C, nrows,
                                     spec.k, spec.k, stride, pad, pm, mode, Ho, Wo, ldc, ldc, act, slope, _dt(x), _stream())
     elif pair is None:
         rc = lib.uig_conv_gather(_p(x), _p(wp), _p(bias), _p(y), B, H, W, C, nrows, spec.k, spec.k, stride, pad, pm, mode,
@@ -264,11 +265,21 @@ def _dy_padded(spec: ConvSpec, dy: torch.Tensor) -> torch.Tensor:
     return to_nhwc(dy.permute(0, 3, 1, 2), dy.dtype, spec.cout_p)
 
 
-def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, pair=None) -> torch.Tensor:
-    """aten::convolution_backward, input gradient.  dy: (B,Ho,Wo,cout_p).  pair = (wp_dgrad2, None, group_images)."""
+def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, pair=None, res_add=None) -> torch.Tensor:
+    """aten::convolution_backward, input gradient.  dy: (B,Ho,Wo,cout_p).  pair = (wp_dgrad2, None, group_images).
+    res_add: a second gradient of the input (the ResBlock skip path's) to be summed in: fused into the launch's epilogue
+    where the kernel supports it, one in-place add otherwise."""
     B, Ho, Wo, Cd = dy.shape
     H, W = in_hw
     s = _stream()
+    if res_add is not None:
+        fusable = (spec.kind == "conv" and spec.reflect and spec.k == 3 and spec.pad == 1 and spec.stride == 1 and H == W and 4 <= H <= 128
+                   and REFLECT_DGRAD_DIRECT and FUSE_SKIP_GRAD and res_add.is_contiguous() and res_add.dtype == dy.dtype
+                   and tuple(res_add.shape) == (B, H, W, spec.cin_p)
+                   and L.lib().uig_conv_strip_applicable(B, Ho, Wo, Cd, spec.cin, H, W, -1, 1, _dt(dy)) == 1)
+        if not fusable:
+            dx = conv_dgrad(spec, dy, wp_dgrad, in_hw, pair)
+            return dx.add_(res_add)
     if spec.kind == "convT":     # gradient of a transposed conv = strided direct conv of dy
         dx = torch.empty((B, H, W, spec.cin_p), device=dy.device, dtype=dy.dtype)
         _gather(dy, wp_dgrad, None, dx, B, Ho, Wo, Cd, spec.cin, spec, spec.stride, spec.pad, L.PAD_ZERO, L.GATHER_DIRECT, H, W,
@@ -286,7 +297,7 @@ def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, 
                                                 _dt(dy), s), "uig_reflect3x3_dgrad_border")
         dx = torch.empty((B, H, W, spec.cin_p), device=dy.device, dtype=dy.dtype)
         _gather(dy, wp_dgrad, None, dx, B, Ho, Wo, Cd, spec.cin, spec, 1, 1, L.PAD_ZERO, L.GATHER_TRANSPOSED, H, W, spec.cin_p,
-                L.ACT_NONE, 0.0, "uig_conv_gather(dgrad+border)", pair, None, bord)
+                L.ACT_NONE, 0.0, "uig_conv_gather(dgrad+border)", pair, None, bord, res_add)
         return dx
     if spec.reflect:             # gradient w.r.t. the reflection-padded input, then fold the border back
         P = spec.pad
@@ -436,6 +447,17 @@ def _param_grads_pair(layers, spec, x, dy, group, colsum, pparts):
     return True
 
 
+class SkipLink:
+    """Side channel of one ResBlock call: the InstanceNorm that adds the residual hands the skip path's gradient (= its incoming
+    gradient) to the block's FIRST convolution, whose input-gradient launch sums it in, instead of returning it to autograd
+    (which would add the two gradients of the block input with a separate full-tensor kernel).  Ordering is given by the
+    graph: the first conv's backward can only run after that norm's backward."""
+    __slots__ = ("grad",)
+
+    def __init__(self):
+        self.grad = None
+
+
 def _conv_backward(ctx, dy, layers, group):
     """Shared backward of ConvFn / PairConvFn.  The input gradient and the parameter gradients are independent given dy:
     the parameter-gradient kernels are forked onto a side stream and joined before returning.  The input-gradient grid
@@ -462,9 +484,13 @@ def _conv_backward(ctx, dy, layers, group):
     defer = _DEFER_JOIN.get(torch.device(dy.device).index, False) and any_p and fused_all and PARALLEL_BACKWARD
     par = (need_x or defer) and any_p and PARALLEL_BACKWARD
     main = torch.cuda.current_stream(dy.device)
+    link = getattr(ctx, "skip_link", None)
+    skip = None
+    if link is not None:
+        skip, link.grad = link.grad, None
     dx = None
     if need_x and not par:
-        dx = conv_dgrad(spec, dy, layers[0].wp_dgrad, ctx.in_hw, pair)
+        dx = conv_dgrad(spec, dy, layers[0].wp_dgrad, ctx.in_hw, pair, skip)
     grads = []
     if par:
         side = _side_stream(dy.device)
@@ -483,7 +509,7 @@ def _conv_backward(ctx, dy, layers, group):
             grads.extend(_param_grads(layer, spec, xs, dys, need_w[i], need_b[i], colsum, i0, pparts[i] if pparts else None))
     if par:
         if need_x:
-            dx = conv_dgrad(spec, dy, layers[0].wp_dgrad, ctx.in_hw, pair)
+            dx = conv_dgrad(spec, dy, layers[0].wp_dgrad, ctx.in_hw, pair, skip)
         if defer:
             # no join here: the side stream keeps working behind the main stream's next ops (InstanceNorm backward, the next
             # layer's input gradient, ...).  The tensors it reads are pinned for the allocator with record_stream; the owner
@@ -493,6 +519,8 @@ def _conv_backward(ctx, dy, layers, group):
                 colsum[0].record_stream(side)
         else:
             main.wait_stream(side)
+    if skip is not None and dx is None:       # input needs no gradient from the conv itself, the skip path's still flows
+        dx = skip
     return (dx, *grads)
 
 
@@ -500,16 +528,16 @@ class ConvFn(Function):
     """y = act(conv(x, W) + b) on physical NHWC tensors; backward = dgrad / wgrad / bias-grad HIP kernels."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, layer):
+    def forward(ctx, x, weight, bias, layer, skip_link=None):
         spec = layer.spec
         y = conv_forward(spec, x, layer.wp_fwd, bias, want_in_stats=layer.emit_in_stats)
-        ctx.layer, ctx.in_hw = layer, (x.shape[1], x.shape[2])
+        ctx.layer, ctx.in_hw, ctx.skip_link = layer, (x.shape[1], x.shape[2]), skip_link
         ctx.save_for_backward(x, y if spec.act != L.ACT_NONE else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        return (*_conv_backward(ctx, dy, (ctx.layer,), 0), None)
+        return (*_conv_backward(ctx, dy, (ctx.layer,), 0), None, None)
 
 
 class PairConvFn(Function):
@@ -518,22 +546,22 @@ class PairConvFn(Function):
     count and doubles the tiles per launch, which is what fills 256 CUs at a per-GPU batch of 4."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, layer1, layer2, group):
+    def forward(ctx, x, w1, b1, w2, b2, layer1, layer2, group, skip_link=None):
         spec = layer1.spec
         y = conv_forward(spec, x, layer1.wp_fwd, b1, pair=(layer2.wp_fwd, b2, group), want_in_stats=layer1.emit_in_stats)
-        ctx.layers, ctx.group, ctx.in_hw = (layer1, layer2), group, (x.shape[1], x.shape[2])
+        ctx.layers, ctx.group, ctx.in_hw, ctx.skip_link = (layer1, layer2), group, (x.shape[1], x.shape[2]), skip_link
         ctx.save_for_backward(x, y if spec.act != L.ACT_NONE else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        return (*_conv_backward(ctx, dy, ctx.layers, ctx.group), None, None, None)
+        return (*_conv_backward(ctx, dy, ctx.layers, ctx.group), None, None, None, None)
 
 
 # ----------------------------------------------------------------------------------------- instance norm (+act, +residual)
 class InstNormActFn(Function):
     @staticmethod
-    def forward(ctx, x, residual, act, slope, eps):
+    def forward(ctx, x, residual, act, slope, eps, skip_link=None):
         _chk_phys(x, "instnorm")
         B, H, W, C = x.shape
         lib = L.lib()
@@ -547,15 +575,19 @@ class InstNormActFn(Function):
         else:
             L.check(lib.uig_instnorm_act_fwd(_p(x), _p(residual), _p(y), _p(stats), _p(ws), B, H * W, C, eps, act, slope,
                                              _dt(x), _stream()), "uig_instnorm_act_fwd")
-        ctx.act, ctx.slope, ctx.has_res = act, slope, residual is not None
+        ctx.act, ctx.slope, ctx.has_res, ctx.skip_link = act, slope, residual is not None, skip_link
         ctx.save_for_backward(x, stats)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, stats = ctx.saved_tensors
-        dx = instnorm_backward(dy.contiguous(), x, stats, ctx.act, ctx.slope)
-        return dx, (dy if ctx.has_res else None), None, None, None
+        dy = dy.contiguous()
+        dx = instnorm_backward(dy, x, stats, ctx.act, ctx.slope)
+        dres = dy if ctx.has_res else None
+        if dres is not None and ctx.skip_link is not None and ctx.needs_input_grad[1]:
+            ctx.skip_link.grad, dres = dres, None       # handed to the block's first conv (SkipLink), not to autograd
+        return dx, dres, None, None, None, None
 
 
 def instnorm_backward(dy, x, stats, act, slope):
