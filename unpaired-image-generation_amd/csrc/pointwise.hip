@@ -209,7 +209,8 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
 template <typename T, int LOSS>
 __global__ __launch_bounds__(256) void loss_partial_kernel(const T* __restrict__ a, const T* __restrict__ b, float target,
                                                             T* __restrict__ grad, float* __restrict__ partial,
-                                                            long nchunks, long tail_start, long n, float gscale) {
+                                                            long nchunks, long tail_start, long n, float gscale,
+                                                            float* __restrict__ loss_single, float loss_scale) {
     constexpr int E = ElemTraits<T>::E;
     __shared__ float sh[4];
     float s = 0.f;
@@ -242,7 +243,10 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(const T* __restrict__
         }
     }
     const float bs = block_sum_256(s, sh);
-    if (threadIdx.x == 0) partial[blockIdx.x] = bs;
+    if (threadIdx.x == 0) {
+        if (loss_single != nullptr) loss_single[0] = bs * loss_scale;      // one-block launch (small tensors): no second kernel
+        else partial[blockIdx.x] = bs;
+    }
 }
 __global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict__ partial, int np, float* __restrict__ loss, double scale) {
     __shared__ double shd[256];
@@ -264,11 +268,14 @@ static int launch_loss(const void* a, const void* b, float target, float* loss, 
     const long nchunks = n / E, tail = nchunks * E;
     const int blocks = grid_for(std::max<long>(nchunks, 1), 2);
     const float gscale = weight / (float)n_real;
-    if (dtype == UIG_BF16) hipLaunchKernelGGL((loss_partial_kernel<bf16_t, LOSS>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, target, (bf16_t*)grad, ws, nchunks, tail, n, gscale);
-    else hipLaunchKernelGGL((loss_partial_kernel<float, LOSS>), dim3(blocks), dim3(256), 0, s, (const float*)a, (const float*)b, target, (float*)grad, ws, nchunks, tail, n, gscale);
+    float* single = blocks == 1 ? loss : nullptr;          // the PatchGAN score maps (900 values per image) fit one block
+    if (dtype == UIG_BF16) hipLaunchKernelGGL((loss_partial_kernel<bf16_t, LOSS>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, target, (bf16_t*)grad, ws, nchunks, tail, n, gscale, single, gscale);
+    else hipLaunchKernelGGL((loss_partial_kernel<float, LOSS>), dim3(blocks), dim3(256), 0, s, (const float*)a, (const float*)b, target, (float*)grad, ws, nchunks, tail, n, gscale, single, gscale);
     UIG_LAUNCH_CHECK(name);
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, ws, blocks, loss, (double)weight / (double)n_real);
-    UIG_LAUNCH_CHECK(name);
+    if (single == nullptr) {
+        hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, ws, blocks, loss, (double)weight / (double)n_real);
+        UIG_LAUNCH_CHECK(name);
+    }
     return 0;
 }
 extern "C" int uig_l1_loss_fwd_bwd(const void* a, const void* b, float* loss, void* grad_a, float* workspace,

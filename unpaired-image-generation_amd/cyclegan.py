@@ -129,19 +129,19 @@ class CycleGAN:
             idt_A, idt_B = self.G_A.forward_phys(xb), self.G_B.forward_phys(xa)
             rec_A, rec_B = self.G_B.forward_phys(fake_B), self.G_A.forward_phys(fake_A)
         n_real = B * xa.shape[1] * xa.shape[2] * 3
-        l_idt_A = ops.l1_loss(idt_A, xb, self.lam * self.lam_idt, n_real)
-        l_idt_B = ops.l1_loss(idt_B, xa, self.lam * self.lam_idt, n_real)
+        l_idt_A = ops.l1_loss(idt_A, xb, self.lam * self.lam_idt, n_real, True)
+        l_idt_B = ops.l1_loss(idt_B, xa, self.lam * self.lam_idt, n_real, True)
         if self.batch_fused and self.paired:
             pd_A, pd_B = torch.split(pair_forward_phys(self.D_A, self.D_B, ff), B)
-            l_G_A, l_G_B = ops.mse_const(pd_A, 1.0), ops.mse_const(pd_B, 1.0)
+            l_G_A, l_G_B = ops.mse_const(pd_A, 1.0, 1.0, True), ops.mse_const(pd_B, 1.0, 1.0, True)
         else:
-            l_G_A = ops.mse_const(self.D_A.forward_phys(fake_B), 1.0)
-            l_G_B = ops.mse_const(self.D_B.forward_phys(fake_A), 1.0)
-        l_cyc_A = ops.l1_loss(rec_A, xa, self.lam, n_real)
-        l_cyc_B = ops.l1_loss(rec_B, xb, self.lam, n_real)
+            l_G_A = ops.mse_const(self.D_A.forward_phys(fake_B), 1.0, 1.0, True)
+            l_G_B = ops.mse_const(self.D_B.forward_phys(fake_A), 1.0, 1.0, True)
+        l_cyc_A = ops.l1_loss(rec_A, xa, self.lam, n_real, True)
+        l_cyc_B = ops.l1_loss(rec_B, xb, self.lam, n_real, True)
         losses = [l_idt_A, l_idt_B, l_G_A, l_G_B, l_cyc_A, l_cyc_B]
         with ops.deferred_param_grads(self.device) if self.defer_join else contextlib.nullcontext():
-            torch.autograd.backward(losses)
+            ops.backward_unit(losses)
         self.grp_D.set_requires_grad(True)
         self.last_fake_B = fake_B.detach()
         return fake_B.detach(), fake_A.detach(), losses
@@ -152,18 +152,18 @@ class CycleGAN:
         out = []
         if self.batch_fused and self.paired:      # D_A on [real_B; fake_B] and D_B on [real_A; fake_A] as one paired pass
             p = torch.split(pair_forward_phys(self.D_A, self.D_B, torch.cat([xb, fake_B, xa, fake_A])), B)
-            ls = [ops.mse_const(p[0], 1.0, 0.5), ops.mse_const(p[1], 0.0, 0.5),
-                  ops.mse_const(p[2], 1.0, 0.5), ops.mse_const(p[3], 0.0, 0.5)]
+            ls = [ops.mse_const(p[0], 1.0, 0.5, True), ops.mse_const(p[1], 0.0, 0.5, True),
+                  ops.mse_const(p[2], 1.0, 0.5, True), ops.mse_const(p[3], 0.0, 0.5, True)]
             with ops.deferred_param_grads(self.device) if self.defer_join else contextlib.nullcontext():
-                torch.autograd.backward(ls)
+                ops.backward_unit(ls)
             return [(ls[0], ls[1]), (ls[2], ls[3])]
         for D, real, fake in ((self.D_A, xb, fake_B), (self.D_B, xa, fake_A)):
             if self.batch_fused:
                 p = D.forward_phys(torch.cat([real, fake]))
-                l_real, l_fake = ops.mse_const(p[:B], 1.0, 0.5), ops.mse_const(p[B:], 0.0, 0.5)
+                l_real, l_fake = ops.mse_const(p[:B], 1.0, 0.5, True), ops.mse_const(p[B:], 0.0, 0.5, True)
             else:
-                l_real, l_fake = ops.mse_const(D.forward_phys(real), 1.0, 0.5), ops.mse_const(D.forward_phys(fake), 0.0, 0.5)
-            torch.autograd.backward([l_real, l_fake])
+                l_real, l_fake = ops.mse_const(D.forward_phys(real), 1.0, 0.5, True), ops.mse_const(D.forward_phys(fake), 0.0, 0.5, True)
+            ops.backward_unit([l_real, l_fake])
             out.append((l_real, l_fake))
         return out
 

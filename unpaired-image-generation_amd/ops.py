@@ -616,7 +616,8 @@ class L1LossFn(Function):
     """weight * mean|a - b| over the n_real unpadded elements; the gradient is produced in the same pass."""
 
     @staticmethod
-    def forward(ctx, a, b, weight, n_real):
+    def forward(ctx, a, b, weight, n_real, unit_grad=False):
+        ctx.unit_grad = unit_grad
         loss = torch.empty((1,), device=a.device, dtype=torch.float32)
         need = ctx.needs_input_grad[0]
         grad = torch.empty_like(a) if need else None
@@ -628,16 +629,19 @@ class L1LossFn(Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
+        if ctx.unit_grad:                # the loss is a root of backward() with gradient 1: the stored gradient IS the answer
+            return grad, None, None, None, None
         out = torch.empty_like(grad)
         L.check(L.lib().uig_scale_by_scalar(_p(grad), _p(g.contiguous().float()), _p(out), grad.numel(), _dt(grad), _stream()), "uig_scale_by_scalar")
-        return out, None, None, None
+        return out, None, None, None, None
 
 
 class MSEConstFn(Function):
     """weight * mean((a - target)^2)  (LSGAN adversarial loss against a constant label)."""
 
     @staticmethod
-    def forward(ctx, a, target, weight):
+    def forward(ctx, a, target, weight, unit_grad=False):
+        ctx.unit_grad = unit_grad
         loss = torch.empty((1,), device=a.device, dtype=torch.float32)
         need = ctx.needs_input_grad[0]
         grad = torch.empty_like(a) if need else None
@@ -649,17 +653,28 @@ class MSEConstFn(Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
+        if ctx.unit_grad:
+            return grad, None, None, None
         out = torch.empty_like(grad)
         L.check(L.lib().uig_scale_by_scalar(_p(grad), _p(g.contiguous().float()), _p(out), grad.numel(), _dt(grad), _stream()), "uig_scale_by_scalar")
-        return out, None, None
+        return out, None, None, None
 
 
-def l1_loss(a, b, weight=1.0, n_real=None):
-    return L1LossFn.apply(a, b, float(weight), int(a.numel() if n_real is None else n_real))
+def l1_loss(a, b, weight=1.0, n_real=None, unit_grad=False):
+    """unit_grad=True: the caller promises the loss is passed to backward() as a root with gradient exactly 1 (the train
+    step does, with an explicit ones tensor); the backward then returns the gradient computed in the forward pass as is."""
+    return L1LossFn.apply(a, b, float(weight), int(a.numel() if n_real is None else n_real), bool(unit_grad))
 
 
-def mse_const(a, target, weight=1.0):
-    return MSEConstFn.apply(a, float(target), float(weight))
+def mse_const(a, target, weight=1.0, unit_grad=False):
+    return MSEConstFn.apply(a, float(target), float(weight), bool(unit_grad))
+
+
+def backward_unit(losses):
+    """torch.autograd.backward(losses) with ONE shared ones tensor as every root's gradient (autograd would otherwise fill a
+    fresh ones_like per root: ten 1-element kernels per train step)."""
+    one = torch.ones((1,), device=losses[0].device, dtype=losses[0].dtype)
+    torch.autograd.backward(losses, grad_tensors=[one] * len(losses))
 
 
 def adam_flat(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
