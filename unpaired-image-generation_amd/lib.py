@@ -80,6 +80,10 @@ def lib() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
+        # A/B switches without rebuilding: UIG_DEBUG_HOOKS="gemv=0,wgrad_rows=0" calls uig_debug_set_<name>(value)
+        for item in filter(None, os.environ.get("UIG_DEBUG_HOOKS", "").split(",")):
+            name, _, val = item.partition("=")
+            getattr(l, "uig_debug_set_" + name.strip())(int(val))
         _lib = l
     return _lib
 
