@@ -381,6 +381,9 @@ int uig_try_conv_strip(const void* x, const void* wp, const float* bias, const v
                        int k, int pad_mode, const int* taps, int ntaps, int dh_min, int dh_max, int Ho, int Wo, int ldc, int Nstore,
                        int act, float slope, int dtype, long x_bytes, long w_bytes, hipStream_t s, int* rc_out);
 
+int uig_try_conv_cin8(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
+                      void* y, int B, int H, int W, int Cin, int Nrows, int pad_mode, const int* taps, int ntaps,
+                      int Ho, int Wo, int ldc, int Nstore, int act, float slope, int dtype, long w_bytes, hipStream_t s, int* rc_out);
 int uig_try_conv_gemv(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
                       void* y, int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad, int pad_mode,
                       int Ho, int Wo, int ldc, int Nstore, int act, float slope, int dtype, hipStream_t s, int* rc_out);
@@ -462,6 +465,12 @@ static int conv_gather_impl(const void* x, const void* wp, const float* bias, co
         int rc = 0;
         if (uig_try_conv_gemv(x, wp, bias, wp2, bias2, group_images, y, B, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode, Ho, Wo, ldc, Nstore,
                               act, slope, dtype, s, &rc))
+            return rc;
+    }
+    if (d.nphase == 1 && stride == 1 && Cin == 8 && in_partial == nullptr && border_add == nullptr && res_add == nullptr) {   // one chunk of input channels per pixel
+        int rc = 0;
+        if (uig_try_conv_cin8(x, wp, bias, wp2, bias2, group_images, y, B, H, W, Cin, Nrows, pad_mode, d.tap, d.ph_tap0[1], Ho, Wo, ldc, Nstore,
+                              act, slope, dtype, (long)d.w_bytes, s, &rc))
             return rc;
     }
     if (d.nphase == 1 && stride == 1 && kH == kW && in_partial == nullptr && border_add == nullptr && res_add == nullptr) {   // few output channels, many taps
