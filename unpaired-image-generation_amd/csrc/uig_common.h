@@ -115,6 +115,9 @@ __device__ __forceinline__ void store_tile_via_lds(const f32x4_t (&acc)[NT][MT],
             }
         }
     }
+    // The tile is written as 8-byte / f32x4 vectors and read back as u32x4: different vector types, which type-based alias
+    // analysis may treat as non-aliasing (seen in conv_cin8.hip: reads scheduled above the writes).  Compiler barrier.
+    asm volatile("" ::: "memory");
     // the scratch is private to the wave: only its own LDS writes must have landed (the compiler inserts lgkmcnt waits)
     constexpr int RPI = 64 / NCH;                      // rows per store instruction (8 for bf16, 4 for f32)
     const int c = lane % NCH, r0 = lane / NCH;
