@@ -198,6 +198,19 @@ int uig_to_nhwc(const void* src, int src_dtype, int64_t sb, int64_t sc, int64_t 
 int uig_from_nhwc(const void* src, int B, int C, int H, int W, int Cp, int dtype,
                   void* dst, int dst_dtype, int64_t sb, int64_t sc, int64_t sh, int64_t sw, void* stream);
 
+/* Input pipeline tail (the upstream recipe is torchvision's Resize(286, BICUBIC) on a PIL image ->
+ * RandomCrop(256) -> RandomHorizontalFlip -> ToTensor -> Normalize(0.5, 0.5)) in one launch over a batch of decoded
+ * images  src u8[B][Hs][Ws][3]  ->  out dtype[B][Ho][Wo][8] (channels 3..7 zero), values (x/255 - 0.5)/0.5.
+ * The resize is separable resampling in Pillow's 8-bit convention (libImaging/Resample.c): horizontal pass, then
+ * vertical pass, each  clip8((2^21 + sum_i px_i * k_i) >> 22)  with integer coefficients k = round(w * 2^22).
+ *   kh int32[Wr][ksh], bh int32[Wr][2] = (first source column, tap count) per resized column; kv/bv likewise per
+ *   resized row; crop_flip int32[B][3] = (x0, y0, flip) in the resized image, DEVICE memory (clamped to the valid range
+ *   by the kernel): out[b][oy][ox] = resized[b][y0+oy][x0 + (flip ? Wo-1-ox : ox)].                              */
+int uig_resize_crop_flip_normalize(const uint8_t* src, int B, int Hs, int Ws,
+                                   const int32_t* kh, const int32_t* bh, int ksh,
+                                   const int32_t* kv, const int32_t* bv, int ksv, int Hr, int Wr,
+                                   const int32_t* crop_flip, void* out, int Ho, int Wo, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,141 @@
+"""GPU parity of the device-side input pipeline and of the inference path, through the C ABI:
+bit-exact against oracle/pipeline_ref.py (itself pinned against Pillow in tests/test_pipeline_cpu.py), and the
+generator-only forward at arbitrary H x W against the stock-torch oracle network."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _expect(imgs, params, load, crop):
+    from oracle import pipeline_ref as P
+    return np.stack([P.augment(im, load, crop, int(p[0]), int(p[1]), bool(p[2])) for im, p in zip(imgs, params)])
+
+
+@pytest.mark.parametrize("hs,ws,load,crop", [(256, 256, 286, 256), (300, 400, 286, 256), (64, 48, 72, 64), (700, 512, 286, 256),
+                                             (286, 286, 286, 286)])
+def test_augment_kernel_bit_exact(hs, ws, load, crop):
+    import unpaired_image_generation_amd.pipeline as pl
+    rng = np.random.default_rng(hs + ws)
+    B = 3
+    imgs = rng.integers(0, 256, (B, hs, ws, 3), dtype=np.uint8)
+    span = load - crop
+    params = np.array([[0, 0, 0], [span, span, 1], [span // 2, span // 3, 1]], np.int32)
+    src = torch.from_numpy(imgs).cuda()
+    exp = _expect(imgs, params, load, crop)
+    out = pl.DeviceAugment(load, crop, True, torch.float32)(src, params).cpu().numpy()
+    assert out.shape == (B, crop, crop, 8)
+    assert np.array_equal(out[..., :3], exp) and not out[..., 3:].any()
+    outb = pl.DeviceAugment(load, crop, True, torch.bfloat16)(src, params).float().cpu()
+    assert torch.equal(outb[..., :3], torch.from_numpy(exp).to(torch.bfloat16).float()) and not outb[..., 3:].any()
+
+
+def test_augment_ragged_list_and_sampled_params():
+    import unpaired_image_generation_amd.pipeline as pl
+    rng = np.random.default_rng(5)
+    imgs = [rng.integers(0, 256, s + (3,), dtype=np.uint8) for s in ((256, 256), (200, 320), (256, 256), (40, 33))]
+    aug = pl.DeviceAugment(286, 256, True, torch.float32, seed=11, rank=0)
+    out = aug([torch.from_numpy(i).cuda() for i in imgs]).cpu().numpy()
+    exp = _expect(imgs, aug.last_params, 286, 256)
+    assert np.array_equal(out[..., :3], exp)
+    # out-of-range crop origins in DEVICE memory are clamped by the kernel, never read out of bounds
+    wild = np.array([[-5, 1000, 0]], np.int32)
+    o2 = aug(torch.from_numpy(imgs[0]).cuda().unsqueeze(0), wild).cpu().numpy()
+    assert np.array_equal(o2[..., :3], _expect(imgs[:1], np.array([[0, 30, 0]]), 286, 256))
+
+
+def test_augment_rejects_bad_arguments():
+    import unpaired_image_generation_amd.pipeline as pl
+    aug = pl.DeviceAugment(286, 256)
+    with pytest.raises(ValueError):
+        aug(torch.zeros(1, 256, 256, 4, dtype=torch.uint8, device="cuda"))
+    with pytest.raises(ValueError):
+        aug(torch.zeros(1, 256, 256, 3, dtype=torch.float32, device="cuda"))
+
+
+def test_loader_end_to_end_feeds_train_step(tmp_path):
+    """folders -> decode threads -> upload -> device augment -> physical batches; the train step takes them as they are
+    and gives the same losses as with the equivalent logical fp32 batch"""
+    from PIL import Image
+    import unpaired_image_generation_amd as u
+    import unpaired_image_generation_amd.pipeline as pl
+    from oracle import pipeline_ref as P
+    rng = np.random.default_rng(1)
+    for d, n, size in (("trainA", 6, (40, 40)), ("trainB", 4, (36, 44))):
+        os.makedirs(tmp_path / d)
+        for i in range(n):
+            Image.fromarray(rng.integers(0, 256, size + (3,), dtype=np.uint8)).save(tmp_path / d / f"{i}.png")
+    ds = pl.UnpairedFolders(str(tmp_path), "train", serial_batches=True)
+    ld = pl.UnpairedLoader(ds, 2, dtype=torch.bfloat16, load_size=72, crop_size=64, shuffle=False, workers=2)
+    assert len(ld) == 3
+    batches = [(a.clone(), b.clone(), ld.aug_A.last_params.copy(), ld.aug_B.last_params.copy()) for a, b in ld]
+    assert len(batches) == 3 and batches[0][0].shape == (2, 64, 64, 8) and batches[0][0].dtype == torch.bfloat16
+    # the last batch against the oracle (last_params belong to the most recently produced batch)
+    xa, xb, pa, pb = batches[-1]
+    ia = [pl.decode_rgb(ds.pair(i)[0]) for i in (4, 5)]
+    ea = np.stack([P.augment(im, 72, 64, int(p[0]), int(p[1]), bool(p[2])) for im, p in zip(ia, pa)])
+    assert torch.equal(xa[..., :3].float().cpu(), torch.from_numpy(ea).to(torch.bfloat16).float())
+    # two ranks split the batch slots without overlap
+    l0 = pl.UnpairedLoader(ds, 1, load_size=72, crop_size=64, shuffle=False, workers=1, rank=0, world=2)
+    l1 = pl.UnpairedLoader(ds, 1, load_size=72, crop_size=64, shuffle=False, workers=1, rank=1, world=2)
+    assert len(l0) == len(l1) == 3
+    torch.manual_seed(0)
+    m1 = u.CycleGAN(n_blocks=2, dtype=torch.bfloat16, use_graph=False)
+    torch.manual_seed(0)
+    m2 = u.CycleGAN(n_blocks=2, dtype=torch.bfloat16, use_graph=True)
+    m2.load_state_dicts(*[n.state_dict() for n in m1.nets()])
+    la = m1.train_step(xa[..., :3].permute(0, 3, 1, 2).float(), xb[..., :3].permute(0, 3, 1, 2).float())
+    lb = m2.train_step(xa, xb)
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-6 + 1e-6 * abs(la[k]), (k, la[k], lb[k])
+
+
+def test_translator_arbitrary_sizes_fp32_vs_oracle():
+    import unpaired_image_generation_amd as u
+    from unpaired_image_generation_amd.inference import Translator
+    from oracle.torch_oracle import Generator as OG, init_weights
+    torch.manual_seed(5)
+    og = init_weights(OG(n_blocks=3))
+    g = u.Generator(n_blocks=3, dtype=torch.float32)
+    g.load_state_dict(og.state_dict())
+    tr = Translator(g)
+    for shape in ((1, 3, 96, 160), (2, 3, 72, 40), (1, 3, 50, 67), (1, 3, 96, 160)):
+        x = torch.rand(*shape) * 2 - 1
+        with torch.no_grad():
+            yref = og(x)
+        y = tr(x.cuda()).cpu()
+        assert y.shape == yref.shape, (y.shape, yref.shape)
+        linf = float((y - yref).abs().max())
+        print(shape, "->", tuple(y.shape), "L-inf", linf)
+        assert linf < 1e-3
+    assert len(tr._graphs) == 3                    # the repeated shape replays its graph
+    assert all(p.grad is None for p in g.parameters())
+    eager = Translator(g, use_graph=False)
+    x = torch.rand(1, 3, 72, 40).cuda() * 2 - 1
+    assert torch.equal(eager(x), tr(x))
+
+
+def test_translator_u8_and_checkpoint(tmp_path):
+    import unpaired_image_generation_amd as u
+    from unpaired_image_generation_amd.inference import Translator
+    torch.manual_seed(3)
+    m = u.CycleGAN(n_blocks=2, dtype=torch.bfloat16, use_graph=False)
+    path = str(tmp_path / "ck.pt")
+    m.save(path)
+    tr = Translator.from_checkpoint(path, "G_B", n_blocks=2)
+    img = torch.randint(0, 256, (2, 64, 80, 3), dtype=torch.uint8, device="cuda")
+    out = tr.translate_u8(img)
+    assert out.shape == (2, 64, 80, 3) and out.dtype == torch.uint8
+    # on the host: a GPU `tensor / 255` multiplies by the rounded reciprocal, the pipeline divides (as ToTensor does)
+    x = ((img.cpu().float() / 255 - 0.5) / 0.5).permute(0, 3, 1, 2).cuda()
+    with torch.no_grad():
+        y = m.G_B(x)
+    ref = ((y.permute(0, 2, 3, 1) + 1) * 127.5).round().clamp(0, 255).to(torch.uint8)
+    assert int((out.int() - ref.int()).abs().max()) <= 1        # same kernels; the final rounding may straddle .5
+    with pytest.raises(ValueError):
+        tr.translate_u8(img.float())
+    with pytest.raises(ValueError):
+        tr(torch.zeros(1, 3, 4, 4, device="cuda"))

@@ -248,10 +248,14 @@ class CycleGAN:
         return torch.cat(lg + [l_D_A, l_D_B])
 
     def to_phys(self, x):
+        """logical (B,3,H,W) -> physical (B,H,W,8) in the compute dtype; a tensor that already is physical (as the
+        device-side input pipeline produces it) passes through untouched."""
+        if x.dim() == 4 and x.shape[3] == 8 and x.shape[1] != 3 and x.dtype == self.dtype:
+            return x
         return ops.to_nhwc(x, self.dtype)
 
     def train_step(self, real_A: torch.Tensor, real_B: torch.Tensor, sync: bool = True):
-        """One optimisation step. real_*: logical (B,3,H,W). Returns the 8 losses (dict of floats, or a device tensor
+        """One optimisation step. real_*: logical (B,3,H,W), or physical (B,H,W,8) batches from pipeline.py. Returns the 8 losses (dict of floats, or a device tensor
         of shape (8,) in LOSS_NAMES order when sync=False)."""
         if self.use_graph:
             from .graph_step import graph_train_step

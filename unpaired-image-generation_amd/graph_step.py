@@ -72,7 +72,7 @@ def _capture(model, real_A, real_B):
 
 def graph_train_step(model, real_A, real_B):
     st = model._graphs
-    if st is None or st.real_A.shape != real_A.shape or st.real_B.shape != real_B.shape:
+    if st is None or st.real_A.shape != real_A.shape or st.real_B.shape != real_B.shape or st.real_A.dtype != real_A.dtype:
         try:
             st = model._graphs = _capture(model, real_A, real_B)
         except RuntimeError as e:

@@ -1,0 +1,120 @@
+"""Inference / export path: generator-only forward at arbitrary H x W.
+
+`Translator` wraps a `Generator`: no autograd state, one HIP graph per input shape (captured on first use, replayed
+afterwards: the ~80 launches of a forward cost one graph launch), inputs either float tensors in [-1, 1] or decoded
+8-bit images.  The kernels are the training ones: the reflection-padded gathers, stride-2 and transposed convolutions and
+InstanceNorm handle any H, W the stock modules accept; a size that is not a multiple of 4 comes back as
+4*ceil(ceil(H/2)/2), exactly what the stock stride-2 Conv2d / ConvTranspose2d(output_padding=1) chain returns.
+"""
+from __future__ import annotations
+
+import collections
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import ops
+from .networks import Generator
+
+
+class Translator:
+    def __init__(self, generator: Generator, use_graph: bool = True, max_shapes: int = 8):
+        self.g = generator
+        self.use_graph = use_graph
+        self.max_shapes = max_shapes
+        self._graphs = collections.OrderedDict()      # (B,H,W) -> (graph, static input, static output)
+        self.dtype = generator.compute_dtype
+        self.device = next(generator.parameters()).device
+        for p in generator.parameters():
+            p.requires_grad_(False)
+        generator.repack()
+        self._ident = {}
+
+    @classmethod
+    def from_checkpoint(cls, path, which="G_A", n_blocks=9, ngf=64, dtype=torch.bfloat16, device="cuda", **kw):
+        """`path`: a `CycleGAN.save` file ('nets' = [G_A, G_B, D_A, D_B] state_dicts; which = 'G_A' (A->B) or 'G_B'), or
+        a bare generator state_dict with the stock nn.Sequential keys ('1.weight', '10.b.1.weight', ...)."""
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+        if "nets" in sd:
+            sd = sd["nets"][{"G_A": 0, "G_B": 1}[which]]
+        g = Generator(3, 3, ngf, n_blocks, dtype=dtype, device=device)
+        g.load_state_dict(sd)
+        return cls(g, **kw)
+
+    def refresh(self):
+        """call after the generator's weights changed in place"""
+        self.g.repack()
+
+    # ------------------------------------------------------------------------------------------------ physical path
+    def _forward_phys(self, xp):
+        with torch.no_grad():
+            return self.g.forward_phys(xp)
+
+    def run_phys(self, xp: torch.Tensor) -> torch.Tensor:
+        """physical (B,H,W,8) -> physical (B,H',W',8); the result of a graph replay is a static buffer that the next
+        call with the same shape overwrites"""
+        if xp.dim() != 4 or xp.shape[3] != 8 or xp.dtype != self.dtype:
+            raise ValueError(f"expected physical (B,H,W,8) {self.dtype}, got {xp.dtype} {tuple(xp.shape)}")
+        B, H, W, _ = xp.shape
+        if H < 8 or W < 8:
+            raise ValueError(f"image {H}x{W} too small for the generator (reflection padding after two down-samplings)")
+        if not self.use_graph:
+            return self._forward_phys(xp)
+        key = (B, H, W)
+        ent = self._graphs.get(key)
+        if ent is None:
+            xin = torch.empty_like(xp).copy_(xp)
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._forward_phys(xin)                     # warm-up: lazy kernel attributes, allocator
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                yout = self._forward_phys(xin)
+            ent = self._graphs[key] = (graph, xin, yout)
+            while len(self._graphs) > self.max_shapes:
+                self._graphs.popitem(last=False)
+        else:
+            self._graphs.move_to_end(key)
+        graph, xin, yout = ent
+        xin.copy_(xp, non_blocking=True)
+        graph.replay()
+        return yout
+
+    # ------------------------------------------------------------------------------------------------- user surface
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        """logical (B,3,H,W) float in [-1, 1] -> (B,3,H',W') float32 in [-1, 1]"""
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"expected (B,3,H,W), got {tuple(x.shape)}")
+        with torch.no_grad():
+            yp = self.run_phys(ops.to_nhwc(x.to(self.device), self.dtype))
+            return ops.from_nhwc(yp, 3, torch.float32)
+
+    def _identity_tables(self, n):
+        if n not in self._ident:
+            b = np.stack([np.arange(n, dtype=np.int32), np.ones(n, np.int32)], 1)
+            k = np.full((n, 1), 1 << 22, np.int32)
+            self._ident[n] = (torch.from_numpy(k).to(self.device), torch.from_numpy(b).to(self.device))
+        return self._ident[n]
+
+    def translate_u8(self, img: torch.Tensor) -> torch.Tensor:
+        """decoded images uint8 (B,H,W,3) on the device -> translated uint8 (B,H',W',3): (x/255-0.5)/0.5 in, round((y+1)*127.5) out"""
+        if img.dim() != 4 or img.shape[3] != 3 or img.dtype != torch.uint8:
+            raise ValueError(f"expected uint8 (B,H,W,3), got {img.dtype} {tuple(img.shape)}")
+        img = img.to(self.device).contiguous()
+        B, H, W, _ = img.shape
+        kh, bh = self._identity_tables(W)
+        kv, bv = self._identity_tables(H)
+        xp = torch.empty((B, H, W, 8), dtype=self.dtype, device=self.device)
+        zero = torch.zeros((B, 3), dtype=torch.int32, device=self.device)
+        L.check(L.lib().uig_resize_crop_flip_normalize(
+            img.data_ptr(), B, H, W, kh.data_ptr(), bh.data_ptr(), 1, kv.data_ptr(), bv.data_ptr(), 1, H, W,
+            zero.data_ptr(), xp.data_ptr(), H, W, L.BF16 if self.dtype == torch.bfloat16 else L.F32, ops._stream()),
+            "uig_resize_crop_flip_normalize")
+        yp = self.run_phys(xp)
+        with torch.no_grad():
+            y = yp[..., :3].float()
+            return ((y + 1.0) * 127.5).round_().clamp_(0, 255).to(torch.uint8)

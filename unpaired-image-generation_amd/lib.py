@@ -67,6 +67,7 @@ SIGNATURES = {
     "uig_adam_flat_graph": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _vp, _f, _vp]),
     "uig_to_nhwc": (_i, [_vp, _i, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "uig_from_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i64, _i64, _i64, _i64, _vp]),
+    "uig_resize_crop_flip_normalize": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
 }
 
 
