@@ -34,9 +34,19 @@ def bicubic_filter(x: float) -> float:
     return 0.0
 
 
-def precompute_coeffs(in_size: int, out_size: int, support: float = 2.0):
+def bilinear_filter(x: float) -> float:
+    """Resample.c `bilinear_filter` (triangle), support 1.0"""
+    x = abs(x)
+    return 1.0 - x if x < 1.0 else 0.0
+
+
+FILTERS = {"bicubic": (bicubic_filter, 2.0), "bilinear": (bilinear_filter, 1.0)}
+
+
+def precompute_coeffs(in_size: int, out_size: int, filt: str = "bicubic"):
     """Resample.c `precompute_coeffs` for the full-image box (in0 = 0, in1 = in_size) + `normalize_coeffs_8bpc`.
     Returns (bounds[out][2] = (xmin, count), kk[out][ksize] int32)."""
+    filter_fn, support = FILTERS[filt]
     scale = filterscale = in_size / out_size
     if filterscale < 1.0:
         filterscale = 1.0
@@ -54,7 +64,7 @@ def precompute_coeffs(in_size: int, out_size: int, support: float = 2.0):
         if xmax > in_size:
             xmax = in_size
         xmax -= xmin
-        w = [bicubic_filter((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        w = [filter_fn((x + xmin - center + 0.5) * ss) for x in range(xmax)]
         ww = 0.0
         for v in w:
             ww += v
@@ -71,12 +81,12 @@ def _clip8(v: np.ndarray) -> np.ndarray:
     return np.clip(v >> PRECISION_BITS, 0, 255)          # arithmetic shift on signed ints, like the C code
 
 
-def resize_bicubic_u8(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+def resize_bicubic_u8(img: np.ndarray, out_h: int, out_w: int, filt: str = "bicubic") -> np.ndarray:
     """Pillow `Image.resize((out_w, out_h), BICUBIC)` for an (H, W, C) uint8 image: horizontal pass, then vertical pass,
     8-bit intermediate.  Pillow skips a pass whose size does not change; an identity pass is exact, so it is simply run."""
     H, W, _ = img.shape
-    bh, kh = precompute_coeffs(W, out_w)
-    bv, kv = precompute_coeffs(H, out_h)
+    bh, kh = precompute_coeffs(W, out_w, filt)
+    bv, kv = precompute_coeffs(H, out_h, filt)
     src = img.astype(np.int64)
     tmp = np.empty((H, out_w, img.shape[2]), np.int64)
     for xx in range(out_w):
@@ -97,9 +107,9 @@ def to_tensor_normalize(img_u8: np.ndarray) -> np.ndarray:
     return (t - np.float32(0.5)) / np.float32(0.5)
 
 
-def augment(img_u8: np.ndarray, load_size: int, crop: int, x0: int, y0: int, flip: bool) -> np.ndarray:
+def augment(img_u8: np.ndarray, load_size: int, crop: int, x0: int, y0: int, flip: bool, filt: str = "bicubic") -> np.ndarray:
     """(H, W, 3) uint8 -> (crop, crop, 3) float32 in [-1, 1]: Resize([load, load], BICUBIC) -> crop at (x0, y0) -> flip."""
-    r = resize_bicubic_u8(img_u8, load_size, load_size)
+    r = resize_bicubic_u8(img_u8, load_size, load_size, filt)
     c = r[y0:y0 + crop, x0:x0 + crop]
     if flip:
         c = c[:, ::-1]
