@@ -12,7 +12,7 @@ def t(fn, n=30):
     e0.record()
     for _ in range(n): fn()
     e1.record(); e1.synchronize(); return e0.elapsed_time(e1) * 1e3 / n
-for tile in (0, 2):
+for tile in (0, 3, 64):
     lib.uig_debug_set_tile(tile if tile else 0)
     for B in (8, 16):
         dy = (torch.rand(B, 64, 64, 256, device="cuda") * 2 - 1).to(dt)

@@ -361,7 +361,12 @@ static int dispatch_igemm(const void* x, const void* wp, const float* bias, void
         const long mt = ((long)d.B * d.Mh * d.Mw + 127) / 128;
         const long tiles = mt * ((d.Nrows + 127) / 128) * d.nphase;
         const int ksteps = (d.ph_tap0[1] - d.ph_tap0[0]) * (d.Cin / BK);
-        if (!small && d.in_partial == nullptr && (g_force_tile == 64 || (g_force_tile == 0 && tiles < 384 && ksteps >= 32 && d.nphase == 1)))
+        // The reflection-border GEMM (8 phases, 12 K-steps, 128 full-width tiles at batch 16) is bound by its column phases'
+        // 32-KB-strided rows, not by the K loop (3-, 4- and 6-stage rings measure the same): half-width tiles put a block on
+        // every CU, 16.8 -> 11.8 us.
+        const bool border = d.compact_out && d.nphase == 8 && tiles <= 256;
+        if (!small && d.in_partial == nullptr &&
+            (g_force_tile == 64 || (g_force_tile == 0 && ((tiles < 384 && ksteps >= 32 && d.nphase == 1) || border))))
             return launch_igemm<T, 128, 64, 2, 2, 2, false>(x, wp, bias, y, d, s);
     }
     const bool wide = g_force_tile == 256;
