@@ -94,6 +94,7 @@ size_t uig_wgrad_workspace_bytes(int Np, int Cq, int kH, int kW, int splits);
 int uig_wgrad_tile_rows(int Np, int Mw, int dtype);
 void uig_debug_set_wgrad_wide(int on);   /* tuning hook: 0 = never use the 256-row tile */
 void uig_debug_set_wgrad_rows(int on);   /* A/B hook: 0 = never use the image-row kernel of the stride-1 3x3 convs */
+void uig_debug_set_tr2(int on);        /* 0: stride-2 transposed layers stay on the generic gather kernel */
 void uig_debug_set_cin8(int on);         /* A/B hook: 0 = never use the LDS-resident-weights kernel of the 8-input-channel 7x7 convs */
 void uig_debug_set_gemv(int on);         /* A/B hook: 0 = never use the one-wave-per-pixel kernel of the 1..4-output-channel convs */
 void uig_debug_set_wgrad_head(int on);   /* A/B hook: 0 = never use the kernel of the 7x7 64 -> <=8 channel output conv */

@@ -424,3 +424,50 @@ def test_fused_instnorm_statistics(kind, cin, cout, k, s, p, pm, H, W, dtype):
     assert not hasattr(c2, "_uig_in_partial") and torch.equal(c1, c2)
     y2 = norm(c2)
     assert (y1.float() - y2.float()).abs().max() <= (2e-5 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("kind,ci,co,hw,B,pair", [("convT", 128, 64, 128, 2, False), ("convT", 256, 128, 64, 3, False),
+                                                    ("convT", 128, 64, 128, 4, True), ("convT", 256, 128, 64, 4, True),
+                                                    ("conv", 64, 128, 256, 2, False), ("conv", 128, 256, 128, 2, True)])
+def test_phase_fused_transposed_kernel_matches_generic(kind, ci, co, hw, B, pair):
+    """conv_tr2.hip (all four output phases of a stride-2 3x3 transposed gather in one block) against the generic gather
+    kernel on the same operands: ConvTranspose2d forward (with fused InstanceNorm statistics where the layer has them) and
+    the input gradient of the stride-2 Conv2d, single and paired launches.  Same MFMA products, different summation
+    order over taps/chunks: bf16 outputs agree to 1 ulp-level tolerance; the statistics partials to 1e-3 relative."""
+    u, ops, networks = _mods()
+    lib = u.lib.lib()
+    torch.manual_seed(7)
+    dt = torch.bfloat16
+    l1 = networks.ConvLayer(kind, ci, co, 3, 2, 1, dtype=dt, device="cuda"); l1.repack()
+    l2 = networks.ConvLayer(kind, ci, co, 3, 2, 1, dtype=dt, device="cuda"); l2.repack()
+    with torch.no_grad():
+        l1.bias.normal_(); l2.bias.normal_()
+    res = {}
+    for mode in (0, 1):
+        lib.uig_debug_set_tr2(mode)
+        try:
+            if kind == "convT":
+                x = (torch.rand(B, hw, hw, ci, device="cuda", generator=torch.Generator("cuda").manual_seed(1)) * 2 - 1).to(dt)
+                pr = (l2.wp_fwd, l2.bias, B // 2) if pair else None
+                out = ops.conv_forward(l1.spec, x, l1.wp_fwd, l1.bias, pr, want_in_stats=True)
+            else:
+                ho = hw // 2
+                dy = (torch.rand(B, ho, ho, co, device="cuda", generator=torch.Generator("cuda").manual_seed(2)) * 2 - 1).to(dt)
+                pr = (l2.wp_dgrad, None, B // 2) if pair else None
+                out = ops.conv_dgrad(l1.spec, dy, l1.wp_dgrad, (hw, hw), pr)
+            torch.cuda.synchronize()
+            res[mode] = out
+        finally:
+            lib.uig_debug_set_tr2(1)
+    ya, yb = res[0], res[1]
+    assert ya.shape == yb.shape
+    d = (ya.float() - yb.float()).abs()
+    scale = float(ya.float().abs().max())
+    assert float(d.max()) <= 0.02 * scale + 1e-3, (float(d.max()), scale)
+    assert float(d.mean()) <= 2e-3 * scale
+    pa, pb = getattr(ya, "_uig_in_partial", None), getattr(yb, "_uig_in_partial", None)
+    assert (pa is None) == (pb is None)
+    if pa is not None:             # fused InstanceNorm partials: same per-image sums after reduction over the slabs
+        assert pa[1] == pb[1]
+        sa = pa[0].view(B, pa[1], ya.shape[3], 2).sum(1); sb = pb[0].view(B, pb[1], yb.shape[3], 2).sum(1)
+        assert torch.allclose(sa, sb, rtol=2e-3, atol=2e-3 * float(sa.abs().max()))

@@ -397,6 +397,11 @@ int uig_try_conv_rowstrip(const void* x, const void* wp, const float* bias, cons
                           int pad_mode, const int* taps, int ntaps, int Ho, int Wo, int ldc, int Nstore, int act, float slope,
                           int dtype, long x_bytes, long w_bytes, hipStream_t s, int* rc_out);
 
+int uig_try_conv_tr2(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
+                     float* in_partial, void* y, int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
+                     const int* ph_tap0, const int* taps, int Ho, int Wo, int ldc, int Nstore, int act, float slope, int dtype,
+                     long x_bytes, long w_bytes, hipStream_t s, int* rc_out);
+
 static int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
 static int conv_gather_impl(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
@@ -466,6 +471,12 @@ static int conv_gather_impl(const void* x, const void* wp, const float* bias, co
         d.in_partial = in_partial;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (gather_mode == UIG_GATHER_TRANSPOSED && border_add == nullptr && res_add == nullptr) {   // stride-2 3x3: all four phases of a tile in one block
+        int rc = 0;
+        if (uig_try_conv_tr2(x, wp, bias, wp2, bias2, group_images, in_partial, y, B, H, W, Cin, Nrows, kH, kW, stride, pad, d.ph_tap0, d.tap,
+                             Ho, Wo, ldc, Nstore, act, slope, dtype, (long)d.x_bytes, (long)d.w_bytes, s, &rc))
+            return rc;
+    }
     if (gather_mode == UIG_GATHER_DIRECT && in_partial == nullptr && border_add == nullptr && res_add == nullptr) {   // 1..4 output channels, wide input: one wave per dot product
         int rc = 0;
         if (uig_try_conv_gemv(x, wp, bias, wp2, bias2, group_images, y, B, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode, Ho, Wo, ldc, Nstore,
