@@ -93,7 +93,7 @@ def main():
     value = world * B * args.steps / dt
     sf = step_flops(S)
     out = {
-        "metric": "images/sec full CycleGAN train step, 3x256x256", "value": round(value, 3), "unit": "images/s",
+        "metric": f"images/sec full CycleGAN train step, 3x{args.size}x{args.size}", "value": round(value, 3), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"CycleGAN train step: 9-block G_A/G_B + 70x70 PatchGAN D_A/D_B, {S}x{S}, "

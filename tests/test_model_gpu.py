@@ -255,3 +255,47 @@ def test_generator_shapes_fwd_bwd_fp32(B, H, W):
         if k.endswith(".weight"):
             r = ref[k].grad
             assert float((p.grad.cpu() - r).norm() / (r.norm() + 1e-30)) < 1e-2, k
+
+
+def test_generator_512_fp32_linf_and_transposed_layers():
+    """BASELINE.json configs[3] (512x512 9-block generator, ConvTranspose2d stress): fp32 forward L-inf < 1e-3 vs the oracle,
+    and the bf16 forward (phase-fused transposed kernel on the 128-wide up-sampling layer, generic kernel on the 256-wide
+    one) within the bf16 tolerance of the 256x256 test."""
+    import unpaired_image_generation_amd as u
+    from oracle.torch_oracle import Generator as OG, init_weights
+    torch.manual_seed(11)
+    og = init_weights(OG(n_blocks=9))
+    x = torch.rand(1, 3, 512, 512) * 2 - 1
+    with torch.no_grad():
+        yref = og(x)
+    g = u.Generator(n_blocks=9, dtype=torch.float32)
+    g.load_state_dict(og.state_dict())
+    with torch.no_grad():
+        y = g(x.cuda()).cpu()
+    linf = float((y - yref).abs().max())
+    print("G9@512 fp32 L-inf:", linf)
+    assert y.shape == (1, 3, 512, 512) and linf < 1e-3
+    gb = u.Generator(n_blocks=9, dtype=torch.bfloat16)
+    gb.load_state_dict(og.state_dict())
+    with torch.no_grad():
+        yb = gb(x.cuda()).cpu()
+    linf_b = float((yb - yref).abs().max())
+    print("G9@512 bf16 L-inf:", linf_b)
+    assert linf_b < 0.12
+
+
+def test_train_step_512_batch2_graph_equals_eager():
+    """configs[3] as a train step: batch 2 at 512x512 (bf16).  Graph replay and eager launches run the same kernels: the
+    8 losses agree exactly over 2 steps and stay finite."""
+    import unpaired_image_generation_amd as u
+    torch.manual_seed(21)
+    a = torch.rand(2, 3, 512, 512, device="cuda") * 2 - 1
+    b = torch.rand(2, 3, 512, 512, device="cuda") * 2 - 1
+    torch.manual_seed(5)
+    m1 = u.CycleGAN(n_blocks=9, dtype=torch.bfloat16, use_graph=False)
+    m2 = u.CycleGAN(n_blocks=9, dtype=torch.bfloat16, use_graph=True)
+    m2.load_state_dicts(*[n.state_dict() for n in m1.nets()])
+    for _ in range(2):
+        l1, l2 = m1.train_step(a, b), m2.train_step(a, b)
+        for k in l1:
+            assert np.isfinite(l1[k]) and l1[k] == l2[k], (k, l1[k], l2[k])
