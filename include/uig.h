@@ -94,6 +94,9 @@ size_t uig_wgrad_workspace_bytes(int Np, int Cq, int kH, int kW, int splits);
 int uig_wgrad_tile_rows(int Np, int Mw, int dtype);
 void uig_debug_set_wgrad_wide(int on);   /* tuning hook: 0 = never use the 256-row tile */
 void uig_debug_set_wgrad_rows(int on);   /* A/B hook: 0 = never use the image-row kernel of the stride-1 3x3 convs */
+/* 1 if a stride-2 3x3 transposed gather of this shape runs on the phase-fused kernel (conv_tr2.hip): such launches may emit
+ * InstanceNorm statistics (in_partial of uig_conv_gather_ex) for 64 output channels too */
+int uig_conv_tr2_applicable(int B, int H, int W, int Cin, int Nrows, int Nstore, int ldc, int dtype);
 void uig_debug_set_tr2(int on);        /* 0: stride-2 transposed layers stay on the generic gather kernel */
 void uig_debug_set_cin8(int on);         /* A/B hook: 0 = never use the LDS-resident-weights kernel of the 8-input-channel 7x7 convs */
 void uig_debug_set_gemv(int on);         /* A/B hook: 0 = never use the one-wave-per-pixel kernel of the 1..4-output-channel convs */

@@ -465,7 +465,9 @@ static int conv_gather_impl(const void* x, const void* wp, const float* bias, co
             UIG_CHECK_ARG(d.ph_tap0[p + 1] > d.ph_tap0[p], "uig_conv_gather: transposed phase %d has no taps (k=%dx%d s=%d p=%d)", p, kH, kW, stride, pad);
     }
     if (in_partial != nullptr) {     // fused InstanceNorm statistics need the full-row LDS epilogue on every wave
-        UIG_CHECK_ARG(Nrows > 64 && Nrows % 64 == 0 && Nstore == Nrows && (d.Mh * d.Mw) % 64 == 0 && Ho % d.so == 0 && Wo % d.so == 0 &&
+        const bool tr2 = gather_mode == UIG_GATHER_TRANSPOSED && kH == 3 && kW == 3 && stride == 2 && pad == 1 && Ho == 2 * H && Wo == 2 * W &&
+                         uig_conv_tr2_applicable(B, H, W, Cin, Nrows, Nstore, ldc, dtype) == 1;      // 64-channel layers: only on the phase-fused kernel
+        UIG_CHECK_ARG((Nrows > 64 || tr2) && Nrows % 64 == 0 && Nstore == Nrows && (d.Mh * d.Mw) % 64 == 0 && Ho % d.so == 0 && Wo % d.so == 0 &&
                       (ldc * (dtype == UIG_BF16 ? 2 : 4)) % 16 == 0 && g_force_tile == 0,
                       "uig_conv_gather_ex: fused IN statistics unsupported for this shape (N=%d, %dx%d)", Nrows, d.Mh, d.Mw);
         d.in_partial = in_partial;

@@ -184,17 +184,26 @@ __global__ __launch_bounds__(512, 2) void conv_tr2_kernel(const bf16_t* __restri
 static int g_tr2_mode = 1;
 extern "C" void uig_debug_set_tr2(int on) { g_tr2_mode = on; }
 
+// shape rule of this kernel (also exported: the host uses it to decide whether a 64-channel transposed layer can emit the
+// following InstanceNorm's statistics from its epilogue)
+extern "C" int uig_conv_tr2_applicable(int B, int H, int W, int Cin, int Nrows, int Nstore, int ldc, int dtype) {
+    if (!g_tr2_mode || dtype != UIG_BF16) return 0;
+    if ((W != 64 && W != 128) || Cin % TR_KC != 0 || Cin < 64) return 0;
+    if (Nrows % 64 != 0 || Nstore != Nrows || (ldc * 2) % 16 != 0 || ldc < Nstore) return 0;
+    const int TI = TR_PIX / W;
+    if (H % TI != 0 || (long)(TI + 1) * W > 2 * TR_PIX) return 0;
+    if ((long)B * (H / TI) * (Nrows / 64) > 0x7fffffffL) return 0;
+    return 1;
+}
+
 // returns 1 if the launch was handled here (*rc_out = status), 0 if the shape is not this kernel's
 int uig_try_conv_tr2(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
                      float* in_partial, void* y, int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
                      const int* ph_tap0, const int* taps, int Ho, int Wo, int ldc, int Nstore, int act, float slope, int dtype,
                      long x_bytes, long w_bytes, hipStream_t s, int* rc_out) {
-    if (!g_tr2_mode || dtype != UIG_BF16 || kH != 3 || kW != 3 || stride != 2 || pad != 1) return 0;
-    if (Ho != 2 * H || Wo != 2 * W || (W != 64 && W != 128) || Cin % TR_KC != 0 || Cin < 64) return 0;
-    if (Nrows % 64 != 0 || Nstore != Nrows || (ldc * 2) % 16 != 0 || ldc < Nstore) return 0;
+    if (kH != 3 || kW != 3 || stride != 2 || pad != 1 || Ho != 2 * H || Wo != 2 * W) return 0;
+    if (!uig_conv_tr2_applicable(B, H, W, Cin, Nrows, Nstore, ldc, dtype)) return 0;
     const int TI = TR_PIX / W;
-    if (H % TI != 0 || (long)(TI + 1) * W > 2 * TR_PIX) return 0;
-    if ((long)B * (H / TI) * (Nrows / 64) > 0x7fffffffL) return 0;
     Tr2Desc d{};
     d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Nrows = Nrows; d.ldw = 9 * Cin; d.ldc = ldc; d.Nstore = Nstore; d.act = act; d.slope = slope;
     d.x_bytes = (unsigned)x_bytes; d.w_bytes = (unsigned)w_bytes; d.TI = TI;

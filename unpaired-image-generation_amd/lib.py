@@ -39,6 +39,7 @@ SIGNATURES = {
     "uig_debug_set_gemv": (None, [_i]),
     "uig_debug_set_cin8": (None, [_i]),
     "uig_debug_set_tr2": (None, [_i]),
+    "uig_conv_tr2_applicable": (_i, [_i] * 8),
     "uig_wgrad_splits": (_i, [_i] * 13),
     "uig_wgrad_partial": (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp]),
     "uig_wgrad_pair_splits": (_i, [_i] * 14),

@@ -225,11 +225,17 @@ def _gather(x, wp, bias, y, B, H, W, C, nrows, spec, stride, pad, pm, mode, Ho, 
     L.check(rc, what)
 
 
-def in_stats_fusable(spec: ConvSpec, H: int, W: int) -> bool:
+def in_stats_fusable(spec: ConvSpec, H: int, W: int, B: int = 1, dtype: torch.dtype = torch.bfloat16) -> bool:
     """can this layer's forward launch also emit the statistics of the InstanceNorm that follows it? (rule of uig_conv_gather_ex)"""
     Ho, Wo = spec.out_hw(H, W)
     grid = Ho * Wo if spec.kind == "conv" else (Ho // spec.stride) * (Wo // spec.stride)
-    return spec.cout > 64 and spec.cout % 64 == 0 and grid % 64 == 0 and spec.act == L.ACT_NONE
+    if spec.cout % 64 != 0 or grid % 64 != 0 or spec.act != L.ACT_NONE:
+        return False
+    if spec.cout > 64:
+        return True
+    # 64 output channels: only the phase-fused transposed kernel has the epilogue for it
+    return spec.kind == "convT" and dtype == torch.bfloat16 and \
+        L.lib().uig_conv_tr2_applicable(B, H, W, spec.cin_p, spec.cout, spec.cout_store, spec.cout_store, L.BF16) == 1
 
 
 def conv_forward(spec: ConvSpec, x: torch.Tensor, wp_fwd: torch.Tensor, bias: torch.Tensor | None, pair=None,
@@ -247,7 +253,7 @@ def conv_forward(spec: ConvSpec, x: torch.Tensor, wp_fwd: torch.Tensor, bias: to
     else:
         mode, pm = L.GATHER_TRANSPOSED, L.PAD_ZERO
     part = None
-    if want_in_stats and in_stats_fusable(spec, H, W):
+    if want_in_stats and in_stats_fusable(spec, H, W, B, x.dtype):
         nslab = Ho * Wo // 64
         part = torch.empty((B * nslab * spec.cout_store * 2,), device=x.device, dtype=torch.float32)
     _gather(x, wp_fwd, bias, y, B, H, W, C, spec.cout, spec, spec.stride, spec.pad, pm, mode, Ho, Wo, spec.cout_store,
