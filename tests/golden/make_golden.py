@@ -56,6 +56,21 @@ def train_step_256():
                                   D_A=1.9957597255706787, D_B=1.6433069705963135)}, f, indent=1)
 
 
+def pipeline_small():
+    """Input-pipeline tail (oracle/pipeline_ref.py, itself pinned against Pillow): two 40x52 images -> resize 72 -> crop 64
+    -> flip -> [-1, 1], and the resized 8-bit image of a 24x20 source produced by Pillow's own Image.resize (a second pin)."""
+    from PIL import Image
+    from oracle import pipeline_ref as P
+    rng = np.random.default_rng(2026)
+    imgs = rng.integers(0, 256, (2, 40, 52, 3), dtype=np.uint8)
+    params = np.array([[0, 8, 0], [5, 2, 1]], np.int32)
+    out = np.stack([P.augment(im, 72, 64, int(p[0]), int(p[1]), bool(p[2])) for im, p in zip(imgs, params)])
+    small = rng.integers(0, 256, (24, 20, 3), dtype=np.uint8)
+    pil = np.asarray(Image.fromarray(small).resize((30, 36), Image.BICUBIC))
+    np.savez_compressed(os.path.join(OUT, "pipeline_64.npz"), imgs=imgs, params=params, out=out, small=small, small_resized_36x30=pil)
+
+
 if __name__ == "__main__":
+    pipeline_small()
     config1(); disc64(); train_step_small(); train_step_256()
     print(sorted(os.listdir(OUT)))

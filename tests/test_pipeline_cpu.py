@@ -101,3 +101,12 @@ def test_unpaired_folders(tmp_path):
     assert pl.decode_rgb(a).shape == (20, 24, 3)
     with pytest.raises(FileNotFoundError):
         pl.UnpairedFolders(str(tmp_path), "test")
+
+
+def test_oracle_matches_committed_golden():
+    """tests/golden/pipeline_64.npz (tests/golden/make_golden.py::pipeline_small): the oracle reproduces its committed outputs
+    and the committed Pillow-resized image"""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pipeline_64.npz"))
+    out = np.stack([P.augment(im, 72, 64, int(p[0]), int(p[1]), bool(p[2])) for im, p in zip(g["imgs"], g["params"])])
+    assert np.array_equal(out, g["out"])
+    assert np.array_equal(P.resize_bicubic_u8(g["small"], 36, 30), g["small_resized_36x30"])

@@ -147,3 +147,10 @@ def test_translator_u8_and_checkpoint(tmp_path):
         tr.translate_u8(img.float())
     with pytest.raises(ValueError):
         tr(torch.zeros(1, 3, 4, 4, device="cuda"))
+
+
+def test_augment_kernel_matches_committed_golden():
+    import unpaired_image_generation_amd.pipeline as pl
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pipeline_64.npz"))
+    out = pl.DeviceAugment(72, 64, True, torch.float32)(torch.from_numpy(g["imgs"]).cuda(), g["params"]).cpu().numpy()
+    assert np.array_equal(out[..., :3], g["out"])
