@@ -77,7 +77,7 @@ __global__ __launch_bounds__(512, 2) void conv_tr2_kernel(const bf16_t* __restri
         for (int pc = wave; pc < npiece_s; pc += 8) {
             const int p = pc * 16 + lr8;                              // strip row = pixel i0 * W + p of the image
             const int gi = i0 + p / W;
-            const unsigned off = gi < d.H ? (unsigned)((((img * d.H + i0) * W + p) * Cin + chunk * TR_KC + ((sl ^ ((p >> 2) & 3)) << 3)) * 2)
+            const unsigned off = gi < d.H ? (unsigned)(((img * d.H + i0) * W + p) * Cin + chunk * TR_KC + ((sl ^ ((p >> 2) & 3)) << 3)) * 2u
                                           : 0xFFFFFFFFu;              // rows below the image: the hardware returns zeros
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)((lds_ptr_t)smem + buf * TR_SBUF + pc * 1024),
                                                      16, (int)off, 0, 0, 0);
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(512, 2) void conv_tr2_kernel(const bf16_t* __restri
             if (pc >= 36) break;
             const int ts = pc >> 2, n = (pc & 3) * 16 + lr8;
             const int widx = __builtin_amdgcn_readfirstlane(d.tap[ts] >> 16);
-            const unsigned off = (unsigned)((((n_base + n) * d.ldw) + widx * Cin + chunk * TR_KC + ((sl ^ ((n >> 2) & 3)) << 3)) * 2);
+            const unsigned off = (unsigned)(((n_base + n) * d.ldw) + widx * Cin + chunk * TR_KC + ((sl ^ ((n >> 2) & 3)) << 3)) * 2u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)((lds_ptr_t)smem + 2 * TR_SBUF + pc * 1024),
                                                      16, (int)off, 0, 0, 0);
         }
