@@ -476,3 +476,38 @@ def test_phase_fused_transposed_kernel_matches_generic(kind, ci, co, hw, B, pair
             assert pa[1] == pb[1]
             sa = pa[0].view(B, pa[1], ya.shape[3], 2).sum(1)
             assert torch.allclose(sa, sb, rtol=2e-3, atol=2e-3 * float(sa.abs().max()))
+
+
+@pytest.mark.parametrize("B,hw,pair,pad_mode", [(2, 256, False, "reflect"), (4, 256, True, "reflect"), (1, 512, False, "reflect"), (2, 256, False, "zero"), (1, 258, False, "reflect")])
+def test_head_taps_on_n_kernel_matches_rowstrip(B, hw, pair, pad_mode):
+    """conv_headrow_kernel (7x7, 64 -> 3: horizontal taps on the MFMA N side + one shift-add) against the row-strip kernel it
+    replaces and against the oracle conv on bf16-rounded operands."""
+    u, ops, networks = _mods()
+    lib = u.lib.lib()
+    torch.manual_seed(3)
+    dt = torch.bfloat16
+    l1 = networks.ConvLayer("conv", 64, 3, 7, 1, 3, pad_mode, act=u.lib.ACT_TANH, dtype=dt, device="cuda"); l1.repack()
+    l2 = networks.ConvLayer("conv", 64, 3, 7, 1, 3, pad_mode, act=u.lib.ACT_TANH, dtype=dt, device="cuda"); l2.repack()
+    with torch.no_grad():
+        l1.weight.mul_(3.0); l1.bias.normal_(); l2.weight.mul_(3.0); l2.bias.normal_()
+    l1.repack(); l2.repack()
+    x = (torch.rand(B, hw, hw, 64, device="cuda") * 2 - 1).to(dt)
+    pr = (l2.wp_fwd, l2.bias, B // 2) if pair else None
+    res = {}
+    for mode in (2, 1):             # row-strip kernel | taps on N (default)
+        lib.uig_debug_set_rowstrip(mode)
+        try:
+            res[mode] = ops.conv_forward(l1.spec, x, l1.wp_fwd, l1.bias, pr)
+            torch.cuda.synchronize()
+        finally:
+            lib.uig_debug_set_rowstrip(1)
+    a, b = res[2].float(), res[1].float()
+    assert a.shape == b.shape == (B, hw, hw, 8)
+    assert float((a - b).abs().max()) <= 1.6e-2 and not b[..., 3:].any()
+    # oracle on the first image (fp32 conv of the bf16-rounded operands)
+    xi = x[:1, :, :, :].float().permute(0, 3, 1, 2).cpu()
+    w = l1.weight.detach().to(dt).float().cpu()
+    xp = F.pad(xi, (3, 3, 3, 3), mode="reflect") if pad_mode == "reflect" else F.pad(xi, (3, 3, 3, 3))
+    ref = torch.tanh(F.conv2d(xp, w, l1.bias.detach().float().cpu()))
+    got = b[:1, :, :, :3].permute(0, 3, 1, 2).cpu()
+    assert float((got - ref).abs().max()) <= 1.6e-2

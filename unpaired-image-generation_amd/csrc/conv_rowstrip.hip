@@ -170,6 +170,184 @@ void conv_rowstrip_kernel(const T* __restrict__ x, const T* __restrict__ wp_, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// <= 4 output channels (the 64 -> 3 head): with the channels alone on the MFMA's 16-wide N side 13 of 16 columns are padding.
+// Put the HORIZONTAL TAPS there instead: per kernel row kh one GEMM  P[s][kw*Nc + co] += X[row ho+kh-3][s][ci] * W[co][kh][kw][ci]
+// over all 262 input pixels s of the segment (N = 7*Nc = 21 of 32 columns used, K accumulates over kh and ci), and ONE
+// shift-add at the end,  y[w][co] = sum_kw P[w + kw][kw*Nc + co],  through LDS.  252 MFMAs per 256 output pixels instead of
+// 784, a quarter of the LDS fragment reads, and a 3-stage DMA ring (48 KB per kernel row) because a kernel row is now only
+// ~0.4 us of math.  bf16, k = 7, zero or reflection padding, taps in natural order.
+// epilogue activation of the <= 4-channel kernels: one thread finishes a whole pixel, so the library tanhf (~150 instructions,
+// measured 2.5 us per output row of a block) is replaced by 1 - 2 / (exp(2x) + 1) on the fast exponential (abs. error ~1e-6,
+// far below the bf16 output's rounding); the padded channels are written as zeros without evaluating anything
+__device__ __forceinline__ float head_act(float v, int act, float slope) {
+    if (act == UIG_ACT_TANH) {
+        const float a = fminf(fabsf(v), 15.f);
+        const float r = 1.f - 2.f / (__expf(2.f * a) + 1.f);
+        return v < 0.f ? -r : r;
+    }
+    return apply_act(v, act, slope);
+}
+
+namespace {
+constexpr int HR_ROWS = 4;                            // output rows per block: 10 input-row strips serve 4 output rows (28 for 4 single rows)
+constexpr int HR_SROWS = 320;                         // strip rows per stage: 262 used, padded so that every wave issues 5 pieces
+constexpr int HR_SBUF = HR_SROWS * 128;               // 40960 B
+constexpr int HR_NST = 3;
+constexpr int HR_WOFF = HR_NST * HR_SBUF;             // weights: 7 kh x 32 (kw, co) rows x 128 B, resident for the block
+constexpr int HR_SMEM = HR_WOFF + 7 * 32 * 128;       // 151552 B
+constexpr int HR_PER = 5;                             // DMA instructions per wave per input row
+}
+
+__global__ __launch_bounds__(512, 2)
+void conv_headrow_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp_, const float* __restrict__ bias_,
+                         bf16_t* __restrict__ y, const RowStripDesc d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l8 = lane >> 3, ls = lane & 7, l16 = lane & 15, q = lane >> 4;
+    const int segs = d.Wo / 256, nrg = (d.Ho + HR_ROWS - 1) / HR_ROWS;
+    int t = blockIdx.x;
+    const int seg = t % segs; t /= segs;
+    const int rg = t % nrg, img = t / nrg;
+    const int w0 = seg * 256, ho0 = rg * HR_ROWS;
+    const int Nc = d.Nrows;
+    const bool refl = d.pad_mode == UIG_PAD_REFLECT;
+    const bool g2 = d.wp2 != nullptr && img >= d.group_images;
+    const bf16_t* wp = g2 ? static_cast<const bf16_t*>(d.wp2) : wp_;
+    const float* bias = g2 ? d.bias2 : bias_;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x), 0, d.x_bytes, 0x00020000);
+
+    // group g = input row ho0 - 3 + g (g = 0 .. ROWS + 5): pixels w0 - 3 .. w0 + 258 as strip rows 0 .. 261
+    constexpr int G = HR_ROWS + 6;
+    auto issue_group = [&](int g, int stage) {
+        const int hi = ho0 - 3 + g;
+        int hr = refl ? reflect_idx(hi, d.H) : hi;
+        const bool hin = (unsigned)hr < (unsigned)d.H;      // (reflected rows of a ragged last row group can still fall outside)
+        hr = hin ? hr : 0;
+        const int rowbase = (img * d.H + hr) * d.W;
+        lds_ptr_t sdst = (lds_ptr_t)smem + stage * HR_SBUF;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int j = wave + 8 * i;
+            const int s = 8 * j + l8;
+            const int wi = w0 - 3 + s;
+            const bool win = (unsigned)wi < (unsigned)d.W;
+            const int wr = refl ? reflect_idx(wi, d.W) : wi;
+            const bool ok = (s < 262) & hin & (refl | win);
+            const unsigned off = ok ? (unsigned)((rowbase + wr) * 64 + ((ls ^ ((s >> 1) & 7)) << 3)) * 2u : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(sdst + j * 1024), 16, (int)off, 0, 0, 0);
+        }
+    };
+    issue_group(0, 0);
+    issue_group(1, 1);
+    // ---- weights -> LDS once: row (kh, j = kw * Nc + co), chunk c at slot c ^ ((j >> 1) & 7); rows j >= 7 * Nc are zero
+    for (int i = tid; i < 7 * 32 * 8; i += 512) {
+        const int c = i & 7, j = (i >> 3) & 31, kh = i >> 8;
+        u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
+        if (j < 7 * Nc) {
+            const int kw = j / Nc, co = j - kw * Nc;
+            v = *reinterpret_cast<const u32x4_t*>(wp + (long)co * d.ldw + (kh * 7 + kw) * 64 + c * 8);
+        }
+        *reinterpret_cast<u32x4_t*>(smem + HR_WOFF + (kh * 32 + j) * 128 + ((c ^ ((j >> 1) & 7)) << 4)) = v;
+    }
+
+    // wave w owns pixel tiles w and w + 8 (strip pixels 16 mt .. 16 mt + 15) and, wave 0, tile 16 (pixels 256 .. 261); both N tiles
+    const int nmt = wave == 0 ? 3 : 2;
+    f32x4_t acc[HR_ROWS][3][2];
+#pragma unroll
+    for (int r = 0; r < HR_ROWS; ++r)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) acc[r][b][a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    unsigned xa[3], wa[2];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const int s = (wave + 8 * b) * 16 + l16;
+        xa[b] = (unsigned)(s * 128 + ((q ^ ((s >> 1) & 7)) << 4));
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int j = a * 16 + l16;
+        wa[a] = (unsigned)(HR_WOFF + j * 128 + ((q ^ ((j >> 1) & 7)) << 4));
+    }
+
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        // loads retire in order: with the newest HR_PER DMA instructions (group g+1) outstanding, group g has landed
+        if (g + 1 < G) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HR_PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (g == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the weight rows written above
+        __builtin_amdgcn_s_barrier();                       // everyone's pieces of group g are in LDS; all waves are past group g-1
+        if (g + 2 < G) issue_group(g + 2, (g + 2) % HR_NST);
+        const unsigned char* sx = smem + (g % HR_NST) * HR_SBUF;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32x4_t xf[3];
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                if (b < nmt) xf[b] = *reinterpret_cast<const u32x4_t*>(sx + (xa[b] ^ (unsigned)(h << 6)));
+#pragma unroll
+            for (int r = 0; r < HR_ROWS; ++r) {
+                constexpr int dummy = 0; (void)dummy;
+                const int kh = g - r;                       // input row ho0-3+g is kernel row kh of output row ho0+r
+                if (kh < 0 || kh > 6) continue;             // compile-time after unrolling
+                u32x4_t wf[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(smem + kh * (32 * 128) + (wa[a] ^ (unsigned)(h << 6)));
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+                    if (b < nmt) {
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+                            acc[r][b][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[a]), __builtin_bit_cast(bf16x8_t, xf[b]),
+                                                                                   acc[r][b][a], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    // ---- per output row: P -> LDS as float [272 pixels][32] (over the strip stages), then shift-add, bias, activation, store
+    float* P = reinterpret_cast<float*>(smem);
+    float bv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bv[c] = (bias != nullptr && c < Nc) ? bias[c] : 0.f;
+#pragma unroll
+    for (int r = 0; r < HR_ROWS; ++r) {
+        __syncthreads();                                    // strips (r = 0) / the previous row's P have been consumed
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            if (b < nmt) {
+                const int s = (wave + 8 * b) * 16 + l16;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) *reinterpret_cast<f32x4_t*>(P + s * 32 + a * 16 + 4 * q) = acc[r][b][a];
+            }
+        __syncthreads();
+        const int ho = ho0 + r;
+        if (tid < 256 && ho < d.Ho) {                       // thread t owns output pixel w0 + t: the pixel leaves as one 16-byte store
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = 0.f;
+#pragma unroll
+            for (int kw = 0; kw < 7; ++kw) {
+                const float* pr = P + (tid + kw) * 32 + kw * Nc;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (c < Nc) v[c] += pr[c];          // static register indices: a runtime-bounded loop spills v[]
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (c < Nc) v[c] = head_act(v[c] + bv[c], d.act, d.slope);      // act(0) == 0 for the pads
+            bf16_t* yp = y + ((long)(img * d.Ho + ho) * d.Wo + w0 + tid) * d.ldc;
+            if (d.Nstore == 8) {
+                *reinterpret_cast<u32x4_t*>(yp) = f32_to_chunk<bf16_t>(v);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) if (c < d.Nstore) yp[c].v = f32_to_bf16(v[c]);
+            }
+        }
+    }
+}
+
 template __global__ void conv_rowstrip_kernel<bf16_t, 7, 8>(const bf16_t*, const bf16_t*, const float*, bf16_t*, const RowStripDesc);
 template __global__ void conv_rowstrip_kernel<float, 7, 8>(const float*, const float*, const float*, float*, const RowStripDesc);
 
@@ -213,6 +391,23 @@ int uig_try_conv_rowstrip(const void* x, const void* wp, const float* bias, cons
     if (R > (k - 1)) return 0;
     d.R = R;
     if (2 * R + 256 > (256 + 7 - 1 + 7) / 8 * 8) return 0;
+    // <= 4 output channels, natural tap order, bf16: taps-on-N formulation
+    bool natural = dtype == UIG_BF16 && g_rowstrip_mode == 1 && Nrows <= 4 && R == 3 && Nstore <= 8 && (ldc & 7) == 0 && Cin == 64;
+    for (int i = 0; i < ntaps && natural; ++i)
+        natural = (taps[i] >> 16) == i && ((taps[i] & 255) - 128) == i / 7 - 3 && (((taps[i] >> 8) & 255) - 128) == i % 7 - 3;
+    if (natural) {
+        static bool attr2 = false;
+        if (!attr2) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_headrow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HR_SMEM);
+            if (e != hipSuccess) { *rc_out = uig_set_error((int)e, "conv_headrow: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return 1; }
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(conv_headrow_kernel, dim3(d.B * ((d.Ho + HR_ROWS - 1) / HR_ROWS) * (d.Wo / 256)), dim3(512), HR_SMEM, s,
+                           (const bf16_t*)x, (const bf16_t*)wp, bias, (bf16_t*)y, d);
+        hipError_t e = hipGetLastError();
+        *rc_out = e == hipSuccess ? 0 : uig_set_error((int)e, "conv_headrow: launch failed: %s", hipGetErrorString(e));
+        return 1;
+    }
     *rc_out = dtype == UIG_BF16 ? launch_rowstrip<bf16_t>(x, wp, bias, y, d, s) : launch_rowstrip<float>(x, wp, bias, y, d, s);
     return 1;
 }
