@@ -201,17 +201,20 @@ constexpr int HR_PER = 5;                             // DMA instructions per wa
 
 __global__ __launch_bounds__(512, 2)
 void conv_headrow_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp_, const float* __restrict__ bias_,
-                         bf16_t* __restrict__ y, const RowStripDesc d) {
+                         bf16_t* __restrict__ y, const RowStripDesc d, int P_, int flip, int segw) {
+    // P_: input pixel of (output o, kernel index k) is o + k - P_ (3: same-size conv; 6: the "full" correlation that yields the
+    // padded input gradient of a 7x7 conv).  flip: kernel index k addresses weight tap 6 - k (transposed gather).  segw: output
+    // pixels per segment (256, or the whole row when it has <= 266 pixels: 266 + 6 strip pixels still fit the 17 MFMA tiles).
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l8 = lane >> 3, ls = lane & 7, l16 = lane & 15, q = lane >> 4;
-    const int segs = d.Wo / 256, nrg = (d.Ho + HR_ROWS - 1) / HR_ROWS;
+    const int segs = (d.Wo + segw - 1) / segw, nrg = (d.Ho + HR_ROWS - 1) / HR_ROWS;
     int t = blockIdx.x;
     const int seg = t % segs; t /= segs;
     const int rg = t % nrg, img = t / nrg;
-    const int w0 = seg * 256, ho0 = rg * HR_ROWS;
+    const int w0 = seg * segw, ho0 = rg * HR_ROWS;
     const int Nc = d.Nrows;
     const bool refl = d.pad_mode == UIG_PAD_REFLECT;
     const bool g2 = d.wp2 != nullptr && img >= d.group_images;
@@ -219,10 +222,10 @@ void conv_headrow_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict_
     const float* bias = g2 ? d.bias2 : bias_;
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x), 0, d.x_bytes, 0x00020000);
 
-    // group g = input row ho0 - 3 + g (g = 0 .. ROWS + 5): pixels w0 - 3 .. w0 + 258 as strip rows 0 .. 261
+    // group g = input row ho0 - P + g (g = 0 .. ROWS + 5): pixels w0 - P .. w0 - P + segw + 5 as strip rows 0 .. segw + 5
     constexpr int G = HR_ROWS + 6;
     auto issue_group = [&](int g, int stage) {
-        const int hi = ho0 - 3 + g;
+        const int hi = ho0 - P_ + g;
         int hr = refl ? reflect_idx(hi, d.H) : hi;
         const bool hin = (unsigned)hr < (unsigned)d.H;      // (reflected rows of a ragged last row group can still fall outside)
         hr = hin ? hr : 0;
@@ -232,10 +235,10 @@ void conv_headrow_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict_
         for (int i = 0; i < 5; ++i) {
             const int j = wave + 8 * i;
             const int s = 8 * j + l8;
-            const int wi = w0 - 3 + s;
-            const bool win = (unsigned)wi < (unsigned)d.W;
+            const int wi = w0 - P_ + s;
             const int wr = refl ? reflect_idx(wi, d.W) : wi;
-            const bool ok = (s < 262) & hin & (refl | win);
+            const bool win = (unsigned)wr < (unsigned)d.W;
+            const bool ok = (s < segw + 6) & hin & win;
             const unsigned off = ok ? (unsigned)((rowbase + wr) * 64 + ((ls ^ ((s >> 1) & 7)) << 3)) * 2u : 0xFFFFFFFFu;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(sdst + j * 1024), 16, (int)off, 0, 0, 0);
         }
@@ -248,7 +251,8 @@ void conv_headrow_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict_
         u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
         if (j < 7 * Nc) {
             const int kw = j / Nc, co = j - kw * Nc;
-            v = *reinterpret_cast<const u32x4_t*>(wp + (long)co * d.ldw + (kh * 7 + kw) * 64 + c * 8);
+            const int wt = flip ? 48 - (kh * 7 + kw) : kh * 7 + kw;
+            v = *reinterpret_cast<const u32x4_t*>(wp + (long)co * d.ldw + wt * 64 + c * 8);
         }
         *reinterpret_cast<u32x4_t*>(smem + HR_WOFF + (kh * 32 + j) * 128 + ((c ^ ((j >> 1) & 7)) << 4)) = v;
     }
@@ -325,7 +329,7 @@ void conv_headrow_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict_
             }
         __syncthreads();
         const int ho = ho0 + r;
-        if (tid < 256 && ho < d.Ho) {                       // thread t owns output pixel w0 + t: the pixel leaves as one 16-byte store
+        if (tid < segw && w0 + tid < d.Wo && ho < d.Ho) {   // thread t owns output pixel w0 + t: the pixel leaves as one 16-byte store
             float v[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) v[c] = 0.f;
@@ -376,7 +380,40 @@ int uig_try_conv_rowstrip(const void* x, const void* wp, const float* bias, cons
                           int pad_mode, const int* taps, int ntaps, int Ho, int Wo, int ldc, int Nstore, int act, float slope,
                           int dtype, long x_bytes, long w_bytes, hipStream_t s, int* rc_out) {
     const int BKe = dtype == UIG_BF16 ? 64 : 32;
-    if (!g_rowstrip_mode || k != 7 || ntaps != 49 || Nrows > 16 || Cin % BKe != 0 || Wo % 256 != 0 || Ho != H || Wo != W) return 0;
+    if (!g_rowstrip_mode || k != 7 || ntaps != 49 || Nrows > 16 || Cin % BKe != 0) return 0;
+    // <= 4 output channels, bf16, Cin == 64: taps-on-N kernel.  Natural taps (direct conv, pad P: dh = kh - P, dw = kw - P) or the
+    // mirrored order of a transposed gather (dh = Pt - kh, dw = Pt - kw: kernel index 6 - kh with P = 6 - Pt): the 7x7 head forward
+    // (P = 3) and the padded input gradient of the 7x7 stem (Pt = 0 -> P = 6, output 6 pixels larger than the input).
+    if (dtype == UIG_BF16 && g_rowstrip_mode == 1 && Nrows <= 4 && Nstore <= 8 && (ldc & 7) == 0 && Cin == 64 && (Wo % 256 == 0 || Wo <= 266)) {
+        const int dh0 = (taps[0] & 255) - 128, dw0 = ((taps[0] >> 8) & 255) - 128;
+        const int flip = dh0 > 0 || (dh0 == 0 && ((taps[48] & 255) - 128) < 0) ? 1 : 0;
+        const int P = flip ? 6 - dh0 : -dh0;
+        bool ok = dh0 == dw0 && P >= 0 && P <= 6 && (pad_mode == UIG_PAD_ZERO || (P <= 3 && H > 3 && W > 3));
+        for (int i = 0; i < ntaps && ok; ++i) {
+            const int kh = flip ? 6 - i / 7 : i / 7, kw = flip ? 6 - i % 7 : i % 7;
+            ok = (taps[i] >> 16) == i && ((taps[i] & 255) - 128) == kh - P && (((taps[i] >> 8) & 255) - 128) == kw - P;
+        }
+        if (ok) {
+            RowStripDesc d{};
+            d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Ho = Ho; d.Wo = Wo; d.k = k; d.pad_mode = pad_mode;
+            d.Nrows = Nrows; d.ldw = ntaps * Cin; d.ldc = ldc; d.Nstore = Nstore; d.act = act; d.slope = slope;
+            d.x_bytes = (unsigned)x_bytes; d.w_bytes = (unsigned)w_bytes;
+            d.wp2 = wp2; d.bias2 = bias2; d.group_images = group_images;
+            static bool attr2 = false;
+            if (!attr2) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_headrow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HR_SMEM);
+                if (e != hipSuccess) { *rc_out = uig_set_error((int)e, "conv_headrow: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return 1; }
+                attr2 = true;
+            }
+            const int segw = Wo % 256 == 0 ? 256 : Wo;
+            hipLaunchKernelGGL(conv_headrow_kernel, dim3(B * ((Ho + HR_ROWS - 1) / HR_ROWS) * ((Wo + segw - 1) / segw)), dim3(512), HR_SMEM, s,
+                               (const bf16_t*)x, (const bf16_t*)wp, bias, (bf16_t*)y, d, P, flip, segw);
+            hipError_t e = hipGetLastError();
+            *rc_out = e == hipSuccess ? 0 : uig_set_error((int)e, "conv_headrow: launch failed: %s", hipGetErrorString(e));
+            return 1;
+        }
+    }
+    if (Wo % 256 != 0 || Ho != H || Wo != W) return 0;
     RowStripDesc d{};
     d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Ho = Ho; d.Wo = Wo; d.k = k; d.pad_mode = pad_mode;
     d.Nrows = Nrows; d.ldw = ntaps * Cin; d.ldc = ldc; d.Nstore = Nstore; d.act = act; d.slope = slope;
@@ -391,23 +428,6 @@ int uig_try_conv_rowstrip(const void* x, const void* wp, const float* bias, cons
     if (R > (k - 1)) return 0;
     d.R = R;
     if (2 * R + 256 > (256 + 7 - 1 + 7) / 8 * 8) return 0;
-    // <= 4 output channels, natural tap order, bf16: taps-on-N formulation
-    bool natural = dtype == UIG_BF16 && g_rowstrip_mode == 1 && Nrows <= 4 && R == 3 && Nstore <= 8 && (ldc & 7) == 0 && Cin == 64;
-    for (int i = 0; i < ntaps && natural; ++i)
-        natural = (taps[i] >> 16) == i && ((taps[i] & 255) - 128) == i / 7 - 3 && (((taps[i] >> 8) & 255) - 128) == i % 7 - 3;
-    if (natural) {
-        static bool attr2 = false;
-        if (!attr2) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_headrow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HR_SMEM);
-            if (e != hipSuccess) { *rc_out = uig_set_error((int)e, "conv_headrow: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return 1; }
-            attr2 = true;
-        }
-        hipLaunchKernelGGL(conv_headrow_kernel, dim3(d.B * ((d.Ho + HR_ROWS - 1) / HR_ROWS) * (d.Wo / 256)), dim3(512), HR_SMEM, s,
-                           (const bf16_t*)x, (const bf16_t*)wp, bias, (bf16_t*)y, d);
-        hipError_t e = hipGetLastError();
-        *rc_out = e == hipSuccess ? 0 : uig_set_error((int)e, "conv_headrow: launch failed: %s", hipGetErrorString(e));
-        return 1;
-    }
     *rc_out = dtype == UIG_BF16 ? launch_rowstrip<bf16_t>(x, wp, bias, y, d, s) : launch_rowstrip<float>(x, wp, bias, y, d, s);
     return 1;
 }
