@@ -478,6 +478,30 @@ def test_phase_fused_transposed_kernel_matches_generic(kind, ci, co, hw, B, pair
             assert torch.allclose(sa, sb, rtol=2e-3, atol=2e-3 * float(sa.abs().max()))
 
 
+@pytest.mark.parametrize("nc", [2, 4])
+def test_head_taps_on_n_kernel_other_channel_counts(nc):
+    """the (kw * Nc + co) column packing of conv_headrow_kernel for Nc = 2 and 4 output channels, against the row-strip kernel"""
+    u, ops, networks = _mods()
+    lib = u.lib.lib()
+    torch.manual_seed(nc)
+    dt = torch.bfloat16
+    l1 = networks.ConvLayer("conv", 64, nc, 7, 1, 3, "reflect", dtype=dt, device="cuda")
+    with torch.no_grad():
+        l1.weight.mul_(3.0); l1.bias.normal_()
+    l1.repack()
+    x = (torch.rand(2, 256, 256, 64, device="cuda") * 2 - 1).to(dt)
+    res = {}
+    for mode in (2, 1):
+        lib.uig_debug_set_rowstrip(mode)
+        try:
+            res[mode] = ops.conv_forward(l1.spec, x, l1.wp_fwd, l1.bias).float()
+            torch.cuda.synchronize()
+        finally:
+            lib.uig_debug_set_rowstrip(1)
+    scale = float(res[2].abs().max())
+    assert float((res[1] - res[2]).abs().max()) <= 1.6e-2 * scale and not res[1][..., nc:].any()
+
+
 @pytest.mark.parametrize("B,hw,pair,pad_mode", [(2, 256, False, "reflect"), (4, 256, True, "reflect"), (1, 512, False, "reflect"), (2, 256, False, "zero"), (1, 258, False, "reflect")])
 def test_head_taps_on_n_kernel_matches_rowstrip(B, hw, pair, pad_mode):
     """conv_headrow_kernel (7x7, 64 -> 3: horizontal taps on the MFMA N side + one shift-add) against the row-strip kernel it
