@@ -535,3 +535,31 @@ def test_head_taps_on_n_kernel_matches_rowstrip(B, hw, pair, pad_mode):
     ref = torch.tanh(F.conv2d(xp, w, l1.bias.detach().float().cpu()))
     got = b[:1, :, :, :3].permute(0, 3, 1, 2).cpu()
     assert float((got - ref).abs().max()) <= 1.6e-2
+
+
+@pytest.mark.parametrize("H,W", [(37, 50), (8, 266), (40, 512), (9, 7)])
+def test_taps_on_n_kernel_odd_sizes_forward_and_padded_gradient(H, W):
+    """conv_headrow_kernel at ragged sizes (row groups of 4 that do not divide H, one segment of up to 266 pixels or 256-pixel
+    segments): the 64 -> 3 forward with reflection padding and the stem's padded input gradient (3 <- 64, mirrored taps),
+    each against the generic kernels (hook rowstrip=0)."""
+    u, ops, networks = _mods()
+    lib = u.lib.lib()
+    torch.manual_seed(H * 1000 + W)
+    dt = torch.bfloat16
+    head = networks.ConvLayer("conv", 64, 3, 7, 1, 3, "reflect", dtype=dt, device="cuda")
+    stem = networks.ConvLayer("conv", 3, 64, 7, 1, 3, "reflect", dtype=dt, device="cuda")
+    with torch.no_grad():
+        head.weight.mul_(3.0); head.bias.normal_(); stem.weight.mul_(3.0)
+    head.repack(); stem.repack()
+    x = (torch.rand(2, H, W, 64, device="cuda") * 2 - 1).to(dt)
+    res = {}
+    for mode in (0, 1):
+        lib.uig_debug_set_rowstrip(mode)
+        try:
+            res[mode] = (ops.conv_forward(head.spec, x, head.wp_fwd, head.bias).float(), ops.conv_dgrad(stem.spec, x, stem.wp_dgrad, (H, W)).float())
+            torch.cuda.synchronize()
+        finally:
+            lib.uig_debug_set_rowstrip(1)
+    for a, b in zip(res[0], res[1]):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 1.6e-2 * (float(a.abs().max()) + 1e-3)
