@@ -7,7 +7,8 @@
 One "step" = one full optimisation step on a per-GPU batch of `--batch` (default 4: BASELINE.json
 configs[1]) synthetic (real_A, real_B) pairs; value = global pairs / second (weak scaling).  Rank 0 prints ONE JSON line
 with the contract fields plus `roofline` (dominant kernel: the 256->256 3x3 ResBlock convolution, HIP-event timed
-here) and, at N=1, `cpu_baseline` (the CPU oracle's train step on this host's cores, bounded sample).
+here), `g_fwd` (the paired generator forward of the step as its own HIP graph: the north_star's MFMA-utilisation target)
+and, at N=1, `cpu_baseline` (the CPU oracle's train step on this host's cores, bounded sample).
 """
 import argparse
 import json
@@ -99,29 +100,60 @@ def main():
         "config": {"workload": f"CycleGAN train step: 9-block G_A/G_B + 70x70 PatchGAN D_A/D_B, {S}x{S}, "
                                f"batch {B}/GPU, {args.dtype} MFMA conv path, fp32 master weights + Adam",
                    "global_batch": world * B, "image": f"3x{S}x{S}", "parallelism": f"dp{world}",
-                   "hip_graph": not args.no_graph},
+                   "hip_graph": model.graph_active},
         "step_tflops": round(sf * B / (ms * 1e-3) / 1e12, 2),
         "step_mfma_frac": round(sf * B / (ms * 1e-3) / (PEAK_BF16 if args.dtype == "bf16" else PEAK_F32), 4),
         "losses": {k: round(v, 4) for k, v in losses.items()},
     }
     if rank == 0:
         out["roofline"] = dominant_kernel_roofline(u, torch, dev, dtype, 4 * B, S // 4, args.kernel_iters)
+        out["g_fwd"] = generator_forward_mfma(u, torch, model, dev, dtype, B, S)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(torch, S)
+            out["cpu_baseline"] = cpu_baseline(torch, S, B)
         print(json.dumps(out), flush=True)
-    # orderly shutdown, then skip interpreter teardown: destroying captured HIP graphs / the RCCL communicator from Python
-    # finalizers in arbitrary order has been seen to abort at exit after the result line was already printed
-    torch.cuda.synchronize(dev)
+    # ordered teardown owned by the product (CycleGAN.close: drain, drop graphs / packers / streams, drain), then the
+    # process group, then a normal interpreter exit
+    model.close()
+    del model
     if dist.is_initialized():
-        try:
-            dist.barrier()
-            dist.destroy_process_group()
-        except Exception as e:      # noqa: BLE001 - shutdown only
-            print(f"[bench] process-group shutdown: {e}", file=sys.stderr)
+        dist.barrier()
+        dist.destroy_process_group()
     sys.stdout.flush(); sys.stderr.flush()
-    profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
-    if not profiled and not os.environ.get("UIG_BENCH_SOFT_EXIT"):     # a profiler needs the normal atexit path to write its output
-        os._exit(0)
+
+
+def generator_forward_mfma(u, torch, model, dev, dtype, B, S):
+    """MFMA utilisation of the 9-block generator FORWARD exactly as the step runs it: G_A || G_B in lockstep over the 4B-image
+    stack [real_B; real_A | real_B; real_A] (fake + identity passes of both generators, paired launches), captured into one HIP
+    graph and replayed back to back between HIP events on the launch stream.  99.10 GFLOP per image at 256^2."""
+    from unpaired_image_generation_amd.networks import pair_forward_phys
+    x = (torch.rand(4 * B, S, S, 8, device=dev) * 2 - 1).to(dtype)
+    x[..., 3:] = 0
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side), torch.no_grad():
+        for _ in range(2):
+            pair_forward_phys(model.G_A, model.G_B, x)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize(dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(g, capture_error_mode="thread_local"):
+        y = pair_forward_phys(model.G_A, model.G_B, x)
+    for _ in range(3):
+        g.replay()
+    n = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        g.replay()
+    e1.record(); e1.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    flops = 4 * B * F_G256 * (S / 256.0) ** 2
+    peak = PEAK_BF16 if dtype == torch.bfloat16 else PEAK_F32
+    assert bool(torch.isfinite(y.float()).all())
+    del g
+    return {"what": f"paired G_A||G_B forward over {4 * B} images {S}x{S} (the step's fake+identity pass), one HIP graph",
+            "ms": round(ms, 4), "tflops": round(flops / (ms * 1e-3) / 1e12, 1), "mfma_frac": round(flops / (ms * 1e-3) / peak, 4),
+            "flops": flops, "target_mfma_frac": 0.40}
 
 
 def dominant_kernel_roofline(u, torch, dev, dtype, nimg, hw, iters):
@@ -148,24 +180,28 @@ def dominant_kernel_roofline(u, torch, dev, dtype, nimg, hw, iters):
     ach = flops / (us * 1e-6)
     # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs,
     # gfx950 FETCH_SIZE x2 correction: scripts/prof_dominant.sh + scripts/pmc_summary.py); null when the shape differs.
-    traffic = None
+    # NOT measured in this run (PMC counters need rocprofv3): quoted from the newest committed profile of the same shape, with its file name
+    traffic_from_profile = None
     try:
         pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_dominant_pmc.json"))
         if pmc and dtype == torch.bfloat16:
             j = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))
             if j.get("images") == nimg and j.get("hw") == hw:
-                traffic = j.get("hbm_bytes_per_launch")
+                traffic_from_profile = {"hbm_bytes_per_launch": j.get("hbm_bytes_per_launch"), "file": "profiles/" + pmc[-1],
+                                        "kernel": j.get("kernel")}
     except OSError:
         pass
     alg = (nimg * hw * hw * 256 * 2) * 2 + 2 * 256 * 2304 * 2
-    return {"kernel": "conv_strip_kernel<%s,256,128> conv3x3 256->256 reflect, paired G_A|G_B launch (ResBlock fwd)" % ("bf16" if dtype == torch.bfloat16 else "f32"),
+    kid = u.lib.lib().uig_debug_last_conv_kernel()
+    kname = {u.lib.K_STRIP_PK: "conv_strip_pk_kernel<%s,448> (256x128 tiles, persistent blocks)", u.lib.K_STRIP256: "conv_strip_kernel<%s,256,128>"}.get(kid, "kernel id %d <%%s>" % kid)
+    return {"kernel": (kname + " conv3x3 256->256 reflect, paired G_A|G_B launch (ResBlock fwd)") % ("bf16" if dtype == torch.bfloat16 else "f32"),
             "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
-            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes/launch", "algorithmic_bytes": alg,
+            "frac": round(ach / peak, 4), "traffic": None, "traffic_from_profile": traffic_from_profile, "algorithmic_bytes": alg,
             "avg_us": round(us, 2), "gemm": f"M={nimg * hw * hw} N=256 K=2304 (2 weight sets)", "flops_per_launch": flops}
 
 
-def cpu_baseline(torch, size):
-    """The CPU oracle's train step (stock torch fp32, B=1) on this host's cores: a bounded sample (about 10-30 s).
+def cpu_baseline(torch, size, batch):
+    """The CPU oracle's train step (stock torch fp32) on this host's cores at the benchmark's own batch: a bounded sample (about 10-30 s).
     Threads = the cores this process may actually use (affinity mask, capped at 16 = the GPU box's CPU share per GPU);
     os.cpu_count() over-reports inside a cgroup and oversubscribing oneDNN makes the step several times slower."""
     from oracle.torch_oracle import CycleGANOracle
@@ -177,8 +213,8 @@ def cpu_baseline(torch, size):
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     o = CycleGANOracle(n_blocks=9)
-    rA = torch.rand(1, 3, size, size) * 2 - 1
-    rB = torch.rand(1, 3, size, size) * 2 - 1
+    rA = torch.rand(batch, 3, size, size) * 2 - 1
+    rB = torch.rand(batch, 3, size, size) * 2 - 1
     print(f"[bench] cpu_baseline: oracle train step on {cores} threads ...", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     o.train_step(rA, rB)                       # first step (includes oneDNN primitive creation)
@@ -191,8 +227,8 @@ def cpu_baseline(torch, size):
         for _ in range(n):
             o.train_step(rA, rB)
         dt = (time.perf_counter() - t0) / n
-    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"CPU oracle (stock torch {torch.__version__} fp32) full train step, B=1 {size}x{size}: "
+    return {"value": round(batch / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"CPU oracle (stock torch {torch.__version__} fp32) full train step, B={batch} {size}x{size}: "
                       + (f"1 warm-up + {n} timed steps" if n else "the first step only (it took > 12 s)")}
 
 

@@ -36,10 +36,20 @@ enum { UIG_PACK_ROW_DIM0 = 0, UIG_PACK_ROW_DIM1 = 1 };
 const char* uig_version(void);
 const char* uig_last_error(void);
 int uig_device_ok(void); /* 1 if a gfx950 device is visible to the HIP runtime */
+/* test hook: the kernel family the calling thread's last uig_conv_gather* launch ran on, so that a parity test can assert it
+ * covers the kernel it means to cover rather than a fallback */
+enum { UIG_K_NONE = 0, UIG_K_IGEMM = 1, UIG_K_STRIP128 = 2, UIG_K_STRIP256 = 3, UIG_K_STRIP_PK = 4, UIG_K_ROWSTRIP = 5,
+       UIG_K_HEADROW = 6, UIG_K_GEMV = 7, UIG_K_CIN8 = 8, UIG_K_TR2 = 9 };
+int uig_debug_last_conv_kernel(void);
 /* tuning / test hook: force the conv tile width for layers with >64 output channels (0 = auto, 128, 256) */
 void uig_debug_set_tile(int bn);
-/* tuning / test hook: 1 (default) = stride-1 3x3 convs use the LDS-resident-strip kernel, 0 = always the generic gather */
+/* tuning / test hook: 1 (default) = stride-1 3x3 convs use the LDS-resident-strip kernels, 0 = always the generic gather,
+ * 2 = 128x128 single-buffer strip tiles, 3 = never the persistent (one block per CU, walks its tiles) 256x128 kernel.
+ * All uig_debug_set_* hooks write process-global selection state: set them before launching, never concurrently with launches. */
 void uig_debug_set_strip(int on);
+/* tuning hook of the persistent strip kernel: dm = DMA issue placement (0 top of the K-step, 1 spread between MFMA groups),
+ * grid = persistent grid size (0 = one block per CU) */
+void uig_debug_set_strip_pk(int dm, int grid);
 /* tuning / test hook: 1 (default) = 7x7 stride-1 convs with <= 16 output channels use the row-strip kernel */
 void uig_debug_set_rowstrip(int on);
 /* diagnostic build hook: device buffer (u64[blocks*8*4]) that receives in-kernel cycle stamps; NULL = off (default) */
@@ -83,6 +93,9 @@ int uig_conv_gather_ex(const void* x, const void* wp, const float* bias, const v
 int uig_reflect3x3_dgrad_border(const void* dy, const void* wp, const void* wp2, int group_images, void* bord,
                                 int B, int H, int W, int C, int Nrows, int ldc, int dtype, void* stream);
 int uig_conv_strip_applicable(int B, int H, int W, int Cin, int Nrows, int Ho, int Wo, int dh_min, int dh_max, int dtype);
+/* which strip kernel that launch runs on: 0 none (generic gather), 128 = 128x128 tiles, 256 = 256x128 tiles one per block,
+ * 257 = 256x128 tiles on persistent blocks (tests assert the variant they mean to cover) */
+int uig_conv_strip_tile(int B, int H, int W, int Cin, int Nrows, int Ho, int Wo, int dh_min, int dh_max, int dtype);
 
 /* aten::convolution_backward(weight grad) — dW partials by split-K MFMA GEMM over pixels, then uig_wgrad_reduce.
  *   part[s][n][tap][c] = sum_{pixels m in split s} P[m][n] * Q[pix(m,tap)][c]

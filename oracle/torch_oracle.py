@@ -77,11 +77,42 @@ def init_weights(net: nn.Module) -> nn.Module:
     return net
 
 
+class OraclePool:
+    """Image history buffer of the CycleGAN recipe [PAPER; Shrivastava et al.], SURVEY.md §8(f) row 1, restated with the
+    stdlib RNG calls of the public recipe: while the pool fills every image is stored and returned; afterwards
+    p = uniform(0, 1); p > 0.5: idx = randint(0, size - 1), the stored image is returned and replaced by the new one;
+    otherwise the new image is returned.  One private random.Random(seed) per pool (the product seeds its pools the same
+    way: pool_B with pool_seed, pool_A with pool_seed + 1).  size 0 = identity."""
+
+    def __init__(self, size: int, seed: int):
+        import random
+        self.size, self.rng, self.images = int(size), random.Random(seed), []
+
+    def query(self, images: torch.Tensor) -> torch.Tensor:
+        if self.size == 0:
+            return images
+        out = []
+        for img in images:
+            img = img.detach().clone()
+            if len(self.images) < self.size:
+                self.images.append(img)
+                out.append(img)
+            elif self.rng.uniform(0, 1) > 0.5:
+                idx = self.rng.randint(0, self.size - 1)
+                out.append(self.images[idx])
+                self.images[idx] = img
+            else:
+                out.append(img)
+        return torch.stack(out)
+
+
 class CycleGANOracle:
-    """The §3.1 train step on stock torch CPU ops.  lambda=10, identity 0.5, LSGAN, Adam(2e-4, .5, .999)."""
+    """The §3.1 train step on stock torch CPU ops.  lambda=10, identity 0.5, LSGAN, Adam(2e-4, .5, .999).
+    §8(f) rows 1-2: optional image pools in front of the discriminators' fake batch and the recipe's LR schedule as a stock
+    torch LambdaLR on both optimisers (constant for n_const epochs, then linear to zero over n_decay)."""
 
     def __init__(self, n_blocks: int = 9, lr: float = 2e-4, lambda_cyc: float = 10.0, lambda_idt: float = 0.5,
-                 dtype=torch.float32):
+                 dtype=torch.float32, pool_size: int = 0, pool_seed: int = 0):
         # Appendix B recipe B2: construct all four (default inits consume RNG), then re-init in this order.
         self.G_A, self.G_B = Generator(n_blocks=n_blocks), Generator(n_blocks=n_blocks)
         self.D_A, self.D_B = Discriminator(), Discriminator()
@@ -90,6 +121,24 @@ class CycleGANOracle:
         self.lam, self.lam_idt = lambda_cyc, lambda_idt
         self.opt_G = torch.optim.Adam(list(self.G_A.parameters()) + list(self.G_B.parameters()), lr=lr, betas=(0.5, 0.999))
         self.opt_D = torch.optim.Adam(list(self.D_A.parameters()) + list(self.D_B.parameters()), lr=lr, betas=(0.5, 0.999))
+        self.pool_B, self.pool_A = OraclePool(pool_size, pool_seed), OraclePool(pool_size, pool_seed + 1)
+        self._sched = None
+
+    def set_epoch(self, epoch: int, n_const: int = 100, n_decay: int = 100):
+        """LR of the 1-based training epoch `epoch` under the recipe's schedule: LambdaLR with
+        lambda(e) = 1 - max(0, e + 1 - n_const) / (n_decay + 1), e = scheduler steps taken (the recipe's epoch_count = 1)."""
+        import warnings
+        from torch.optim.lr_scheduler import LambdaLR
+        lam = lambda e: 1.0 - max(0, e + 1 - n_const) / float(n_decay + 1)
+        if self._sched is None or self._sched[0] != (n_const, n_decay):
+            self._sched = ((n_const, n_decay), [LambdaLR(o, lr_lambda=lam) for o in (self.opt_G, self.opt_D)])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")          # "scheduler.step() before optimizer.step()": the order is the caller's business here
+            for sch in self._sched[1]:
+                if sch.last_epoch > epoch - 1:
+                    raise ValueError("the oracle's schedule only moves forward")
+                while sch.last_epoch < epoch - 1:
+                    sch.step()
 
     def nets(self):
         return (self.G_A, self.G_B, self.D_A, self.D_B)
@@ -119,8 +168,9 @@ class CycleGANOracle:
         # --- discriminators
         self._req((self.D_A, self.D_B), True)
         self.opt_D.zero_grad()
-        l_D_A = 0.5 * (mse(self.D_A(real_B), 1.0) + mse(self.D_A(fake_B.detach()), 0.0)); l_D_A.backward()
-        l_D_B = 0.5 * (mse(self.D_B(real_A), 1.0) + mse(self.D_B(fake_A.detach()), 0.0)); l_D_B.backward()
+        pf_B, pf_A = self.pool_B.query(fake_B.detach()), self.pool_A.query(fake_A.detach())
+        l_D_A = 0.5 * (mse(self.D_A(real_B), 1.0) + mse(self.D_A(pf_B), 0.0)); l_D_A.backward()
+        l_D_B = 0.5 * (mse(self.D_B(real_A), 1.0) + mse(self.D_B(pf_A), 0.0)); l_D_B.backward()
         self.opt_D.step()
         self.last = dict(fake_B=fake_B.detach(), fake_A=fake_A.detach(), rec_A=rec_A.detach(), rec_B=rec_B.detach())
         return {"idt_A": l_idt_A.item(), "idt_B": l_idt_B.item(), "G_A": l_G_A.item(), "G_B": l_G_B.item(),

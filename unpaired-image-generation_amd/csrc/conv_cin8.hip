@@ -216,12 +216,12 @@ int uig_try_conv_cin8(const void* x, const void* wp, const float* bias, const vo
     const int nrg = (Ho + d.rpb - 1) / d.rpb;
     const size_t smem = 64 * C8_WROW + C8_RING * C8_RINGW + 4 * 1024;
     if (KR != 7) return 0;                                     // only the 7-row stencil is instantiated
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_cin8_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    static SmemAttrOnce attr_once;
+    {
+        hipError_t e = attr_once.ensure(reinterpret_cast<const void*>(conv_cin8_kernel<7>), (size_t)(int)smem);
         if (e != hipSuccess) { *rc_out = uig_set_error((int)e, "conv_cin8: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return 1; }
-        attr_done = true;
     }
+    uig_note_conv_kernel(UIG_K_CIN8);
     hipLaunchKernelGGL(conv_cin8_kernel<7>, dim3(B * nrg * nseg), dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)wp, bias, (bf16_t*)y, d);
     hipError_t e_ = hipGetLastError();
     *rc_out = e_ == hipSuccess ? 0 : uig_set_error((int)e_, "uig_conv_gather(cin8): launch failed: %s", hipGetErrorString(e_));

@@ -81,6 +81,7 @@ int uig_try_conv_gemv(const void* x, const void* wp, const float* bias, const vo
     d.group_images = group_images; d.wp2 = wp2; d.bias2 = bias2;
     const long M = (long)B * Ho * Wo;
     const int blocks = (int)std::min<long>((M + 3) / 4, 16384);
+    uig_note_conv_kernel(UIG_K_GEMV);
     if (dtype == UIG_BF16) hipLaunchKernelGGL((conv_gemv_kernel<bf16_t, 4>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)wp, bias, (bf16_t*)y, d);
     else hipLaunchKernelGGL((conv_gemv_kernel<float, 4>), dim3(blocks), dim3(256), 0, s, (const float*)x, (const float*)wp, bias, (float*)y, d);
     hipError_t e_ = hipGetLastError();

@@ -326,11 +326,10 @@ static int launch_igemm(const void* x, const void* wp, const float* bias, void* 
     const int nt = (d.Nrows + BN - 1) / BN;
     const size_t smem = NSTAGE * (size_t)(BM + BN) * 128;
     auto kern = igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, NSTAGE, SMALL>;
-    static bool attr_done = false;   // benign race: idempotent
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    static SmemAttrOnce attr_once;
+    {
+        hipError_t e = attr_once.ensure(reinterpret_cast<const void*>(kern), (size_t)(int)smem);
         if (e != hipSuccess) return uig_set_error((int)e, "igemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(mt * nt, d.nphase), dim3(64 * WAVES_M * WAVES_N), smem, s,
                        (const T*)x, (const T*)wp, bias, (T*)y, d);
@@ -519,6 +518,7 @@ static int conv_gather_impl(const void* x, const void* wp, const float* bias, co
         }
         d.wp2 = wp2; d.bias2 = bias2; d.group_rows = (int)grows;
     }
+    uig_note_conv_kernel(UIG_K_IGEMM);
     return dtype == UIG_BF16 ? dispatch_igemm<bf16_t>(x, wp, bias, y, d, s) : dispatch_igemm<float>(x, wp, bias, y, d, s);
 }
 

@@ -363,11 +363,10 @@ static int launch_rowstrip(const void* x, const void* wp, const float* bias, voi
     constexpr int SROWS = (256 + 7 - 1 + 7) / 8 * 8;
     const size_t smem = 2 * (size_t)(SROWS * 128 + 7 * 16 * 128);
     auto kern = conv_rowstrip_kernel<T, 7, 8>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    static SmemAttrOnce attr_once;
+    {
+        hipError_t e = attr_once.ensure(reinterpret_cast<const void*>(kern), (size_t)(int)smem);
         if (e != hipSuccess) return uig_set_error((int)e, "conv_rowstrip: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(d.B * d.Ho * (d.Wo / 256)), dim3(512), smem, s, (const T*)x, (const T*)wp, bias, (T*)y, d);
     UIG_LAUNCH_CHECK("uig_conv_gather(rowstrip)");
@@ -399,12 +398,12 @@ int uig_try_conv_rowstrip(const void* x, const void* wp, const float* bias, cons
             d.Nrows = Nrows; d.ldw = ntaps * Cin; d.ldc = ldc; d.Nstore = Nstore; d.act = act; d.slope = slope;
             d.x_bytes = (unsigned)x_bytes; d.w_bytes = (unsigned)w_bytes;
             d.wp2 = wp2; d.bias2 = bias2; d.group_images = group_images;
-            static bool attr2 = false;
-            if (!attr2) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_headrow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HR_SMEM);
+            static SmemAttrOnce attr_once2;
+            {
+                hipError_t e = attr_once2.ensure(reinterpret_cast<const void*>(conv_headrow_kernel), (size_t)HR_SMEM);
                 if (e != hipSuccess) { *rc_out = uig_set_error((int)e, "conv_headrow: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return 1; }
-                attr2 = true;
             }
+            uig_note_conv_kernel(UIG_K_HEADROW);
             const int segw = Wo % 256 == 0 ? 256 : Wo;
             hipLaunchKernelGGL(conv_headrow_kernel, dim3(B * ((Ho + HR_ROWS - 1) / HR_ROWS) * ((Wo + segw - 1) / segw)), dim3(512), HR_SMEM, s,
                                (const bf16_t*)x, (const bf16_t*)wp, bias, (bf16_t*)y, d, P, flip, segw);
@@ -428,6 +427,7 @@ int uig_try_conv_rowstrip(const void* x, const void* wp, const float* bias, cons
     if (R > (k - 1)) return 0;
     d.R = R;
     if (2 * R + 256 > (256 + 7 - 1 + 7) / 8 * 8) return 0;
+    uig_note_conv_kernel(UIG_K_ROWSTRIP);
     *rc_out = dtype == UIG_BF16 ? launch_rowstrip<bf16_t>(x, wp, bias, y, d, s) : launch_rowstrip<float>(x, wp, bias, y, d, s);
     return 1;
 }

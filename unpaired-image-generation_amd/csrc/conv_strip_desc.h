@@ -1,0 +1,188 @@
+// conv_strip_desc.h — launch descriptor and MFMA wrapper shared by the strip-convolution kernels (conv_strip.hip, conv_strip_pk.hip).
+#pragma once
+#include "uig_common.h"
+
+struct StripDesc {
+    int B, H, W, Cin;        // input  (B, H, W, Cin)
+    int Ho, Wo;              // output (B, Ho, Wo, ldc): one GEMM row per output pixel
+    int pad_mode;
+    int dh_min, dh_max;
+    int Nrows, ldw, ldc, Nstore;
+    int act; float slope;
+    unsigned x_bytes, w_bytes;
+    int tap[16];             // (dh + 128) | (dw + 128) << 8 | weight-tap-index << 16
+    const void* wp2;         // paired launch: images >= group_images use wp2 / bias2
+    const float* bias2;
+    int group_images;
+    float* in_partial;       // optional: InstanceNorm partial statistics [img][HoWo/64][Nstore][2]
+    const void* res_add;     // optional: tensor of y's shape added to the output in the epilogue (the ResBlock skip gradient in dgrad)
+    const void* border_add;  // optional: bord[B][8][S][ldc] of uig_reflect3x3_dgrad_border, added to rows 1 / H-2 and cols 1 / W-2
+    unsigned long long* dbg; // diagnostic build only (STAMP): per-wave cycle sums {wait+barrier, DMA issue, reads+MFMA, total}
+    int wo_magic;            // persistent kernel: ceil(2^20 / Wo), set by uig_launch_strip_pk
+};
+
+template <typename T> struct MmaS;
+template <> struct MmaS<bf16_t> {
+    static __device__ __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct MmaS<float> {
+    static __device__ __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b[e]), c, 0, 0, 0);
+    }
+};
+
+
+// Epilogue of one BM x BN strip tile, shared by conv_strip.hip and conv_strip_pk.hip: bias (+ activation), optional reflection-border /
+// residual adds, optional InstanceNorm partial statistics; full-row stores through this wave's 64x64 LDS scratch when its 64
+// channels are all stored, else direct 8/16-byte stores.  The caller has made sure (barrier) that `scratch` is free.
+template <typename T, int MT, int NT, int WM, int WN>
+__device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], unsigned char* scratch, const StripDesc& d, T* __restrict__ y,
+                                               const float* __restrict__ bias, int img, int p0, int wm, int wn, int n_base, int lane) {
+    const int HoWo = d.Ho * d.Wo;
+    const int l16 = lane & 15, q = lane >> 4;
+    // ---- epilogue: full-row stores through LDS when this wave's 64 channels are all stored, else direct 8/16-byte stores
+    const bool vec_ok = ((d.Nstore & 3) == 0) && ((d.ldc & 3) == 0);
+    const int nw0 = n_base + wn * WN;
+    if (MT == 4 && NT == 4 && vec_ok && nw0 + 64 <= d.Nstore && (d.ldc * (int)sizeof(T)) % 16 == 0) {      // wave-uniform choice
+        float b4[NT * 4];
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = nw0 + a * 16 + 4 * q + e;
+                b4[a * 4 + e] = (bias != nullptr && n < d.Nrows) ? bias[n] : 0.f;
+            }
+        const int pw = p0 + wm * WM;
+        T* ybase = y + (long)img * HoWo * d.ldc + nw0;
+        float* so = nullptr;
+        if (d.in_partial != nullptr && pw < HoWo)
+            so = d.in_partial + (((long)img * ((HoWo + 63) / 64) + pw / 64) * d.Nstore + nw0) * 2;
+        auto rowp = [&](int r) -> T* { const int p = pw + r; return p < HoWo ? ybase + (long)p * d.ldc : nullptr; };
+        if (d.border_add == nullptr && d.res_add == nullptr) {
+            store_tile_via_lds<T, MT, NT>(acc, scratch, lane, b4, d.act, d.slope, rowp, so, min(64, HoWo - pw));
+        } else {
+            // reflection-pad dgrad: add the mirrored-border terms (phases T,B,L,R,TL,TR,BL,BR of the compact border buffer)
+            constexpr int E = ElemTraits<T>::E;
+            const int S = d.Ho;                                   // square map
+            const T* bimg = static_cast<const T*>(d.border_add) + (long)img * 8 * S * d.ldc + nw0;
+            if constexpr (sizeof(T) == 2) {
+                // bf16: all border chunks of this lane's 8 store rows are fetched NOW (3 range-checked buffer loads per row:
+                // line term, column term, corner; an out-of-range offset returns zeros, so no branches), and their latency
+                // hides behind the LDS transposition.  Loading them inside the store loop cost the kernel 9-20 us.
+                const bool hasb = d.border_add != nullptr, hasr = d.res_add != nullptr;
+                const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<void*>(hasb ? d.border_add : d.res_add), 0, hasb ? (unsigned)((long)d.B * 8 * S * d.ldc * (int)sizeof(T)) : 0u, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<void*>(hasr ? d.res_add : d.border_add), 0, hasr ? (unsigned)((long)d.B * HoWo * d.ldc * (int)sizeof(T)) : 0u, 0x00020000);
+                constexpr int NI = 8;                                  // 64 rows / 8 rows per store instruction
+                const int c = lane % 8, r0 = lane / 8;
+                u32x4_t pre[NI][4];                                    // line term, column term, corner, residual tensor
+                // rows i < NI/2 are fetched before the transposition (while the accumulators are live), rows i >= NI/2 in its
+                // mid hook, when the accumulators are dead: 64 fewer live registers at the peak, and the second half's latency
+                // hides behind the first half's row reads and stores
+                auto fetch = [&](int i) {
+                    const int p = pw + r0 + 8 * i;
+                    const int h = p / d.Wo, w = p - h * d.Wo;
+                    const bool ok = p < HoWo;
+                    const bool okb = ok & hasb;
+                    const bool rt_ = okb & (h == 1), rb_ = okb & (h == S - 2), cl_ = okb & (w == 1), cr_ = okb & (w == S - 2);
+                    auto off = [&](bool on, int phase, int pos) -> int {
+                        return on ? (int)(((((long)img * 8 + phase) * S + pos) * d.ldc + nw0 + c * E) * (long)sizeof(T)) : -1;
+                    };
+                    pre[i][0] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsb, off(rt_ | rb_, rt_ ? 0 : 1, w), 0, 0));
+                    pre[i][1] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsb, off(cl_ | cr_, cl_ ? 2 : 3, h), 0, 0));
+                    pre[i][2] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                        rsb, off((rt_ | rb_) & (cl_ | cr_), (rt_ ? 4 : 6) + (cr_ ? 1 : 0), 0), 0, 0));
+                    pre[i][3] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                        rsr, ok ? (int)((((long)img * HoWo + p) * d.ldc + nw0 + c * E) * (long)sizeof(T)) : -1, 0, 0));
+                };
+#pragma unroll
+                for (int i = 0; i < NI / 2; ++i) fetch(i);
+                auto mid = [&]() {
+#pragma unroll
+                    for (int i = NI / 2; i < NI; ++i) fetch(i);
+                };
+                auto add = [&](int, int, const u32x4_t& v, int i) -> u32x4_t {
+                    float f[E], g[E];
+                    chunk_to_f32<T>(v, f);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        chunk_to_f32<T>(pre[i][k], g);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) f[e] += g[e];
+                    }
+                    return f32_to_chunk<T>(f);
+                };
+                store_tile_via_lds<T, MT, NT>(acc, scratch, lane, b4, d.act, d.slope, rowp, so,
+                                              min(64, HoWo - pw), add, mid);
+            } else {
+            auto add = [&](int r, int c, const u32x4_t& v, int) -> u32x4_t {
+                const int p = pw + r;
+                if (p >= HoWo) return v;
+                float f[E], g[E];
+                chunk_to_f32<T>(v, f);
+                if (d.res_add != nullptr) {
+                    chunk_to_f32<T>(*reinterpret_cast<const u32x4_t*>(static_cast<const T*>(d.res_add) + ((long)img * HoWo + p) * d.ldc + nw0 + c * E), g);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) f[e] += g[e];
+                }
+                const int h = p / d.Wo, w = p - h * d.Wo;
+                const bool bd = d.border_add != nullptr;
+                const bool rt_ = bd & (h == 1), rb_ = bd & (h == S - 2), cl_ = bd & (w == 1), cr_ = bd & (w == S - 2);
+                auto acc_from = [&](int phase, int pos) {
+                    chunk_to_f32<T>(*reinterpret_cast<const u32x4_t*>(bimg + ((long)phase * S + pos) * d.ldc + c * E), g);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) f[e] += g[e];
+                };
+                if (rt_) acc_from(0, w);
+                if (rb_) acc_from(1, w);
+                if (cl_) acc_from(2, h);
+                if (cr_) acc_from(3, h);
+                if (rt_ & cl_) acc_from(4, 0);
+                if (rt_ & cr_) acc_from(5, 0);
+                if (rb_ & cl_) acc_from(6, 0);
+                if (rb_ & cr_) acc_from(7, 0);
+                return f32_to_chunk<T>(f);
+            };
+            store_tile_via_lds<T, MT, NT>(acc, scratch, lane, b4, d.act, d.slope, rowp, so,
+                                          min(64, HoWo - pw), add);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < MT; ++b) {
+            const int p = p0 + wm * WM + b * 16 + l16;
+            if (p >= HoWo) continue;
+            T* yp = y + ((long)img * HoWo + p) * d.ldc;
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+                const int n = n_base + wn * WN + a * 16 + 4 * q;
+                if (n >= d.Nstore) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float bv = (bias != nullptr && n + e < d.Nrows) ? bias[n + e] : 0.f;
+                    v[e] = apply_act(acc[a][b][e] + bv, d.act, d.slope);
+                }
+                if (vec_ok) {
+                    if constexpr (sizeof(T) == 4) {
+                        *reinterpret_cast<f32x4_t*>(yp + n) = f32x4_t{v[0], v[1], v[2], v[3]};
+                    } else {
+                        u32x2_t pk;
+                        pk[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                        pk[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                        *reinterpret_cast<u32x2_t*>(yp + n) = pk;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < d.Nstore) ElemTraits<T>::st(yp + n + e, v[e]);
+                }
+            }
+        }
+    }
+}

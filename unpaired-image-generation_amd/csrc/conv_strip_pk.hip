@@ -1,0 +1,283 @@
+// conv_strip_pk.hip — persistent form of the LDS-resident-strip convolution (conv_strip.hip) for its dominant shape: 256 output
+// pixels x 128 channels per tile, 8 waves, stride-1 3x3, forward and input gradient of the ResBlock convs.
+//
+// What the one-tile-per-block kernel leaves on the table (in-kernel s_memtime stamps): the paired ResBlock launch is
+// 512 tiles = exactly two rounds of one 149.5-KB block per CU, and in each round the tile's prologue (row table, first strip
+// chunk, first weight tile: ~6 us), its epilogue (~5.6 us) and the block hand-over are fully exposed: 34 % of the launch.
+// Here the grid is one block per CU and a block WALKS its tiles (tile = round * gridDim + XCD-remapped block id):
+//   * the next tile's first strip chunk and first weight tile are streamed in (LDS-DMA) behind the current tile's LAST chunk
+//     of MFMAs, exactly like a chunk switch inside a tile, so a tile's K loop starts the moment the previous epilogue ends;
+//   * the epilogue's LDS scratch lives in the region the last K-step has just finished with ([strip s][weights s], contiguous),
+//     the prefetch targets the other region: no extra LDS;
+//   * the per-lane row table depends only on the tile's position inside its image, and the tiles a block walks are a whole
+//     number of images apart in the common shapes: it is computed once per block, not once per tile;
+//   * LDS swizzle: slot = (chunk + (row & 6)) & 7 — a rotation instead of the XOR of conv_igemm.hip.  The XOR form is
+//     conflict-free for the 16-row-aligned fragment reads of a GEMM tile but 2-way conflicted for the +-1-pixel SHIFTED reads
+//     that generate the dw = +-1 taps (6 of 9 taps: SQ_LDS_BANK_CONFLICT was 26 % of the LDS cycles of the round-1 kernel);
+//     the rotation is conflict-free at every shift (bank analysis in DESIGN.md §3.2).
+//   * DMA issue is spread between the MFMA groups of a K-step (DM = 1) instead of all 8 waves issuing their 3 pieces at the
+//     top of the step while the matrix pipe idles.
+#include "conv_strip_desc.h"
+#include <algorithm>
+
+template <typename T, int CAP, int DM>
+__global__ __launch_bounds__(512, 2)
+void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, const float* __restrict__ bias1, T* __restrict__ y,
+                          const StripDesc d) {
+    constexpr int E = ElemTraits<T>::E;
+    constexpr int BK = 8 * E;
+    constexpr int BM = 256, BN = 128, NW = 8, NTAPS = 9, WM = 64, WN = 64, MT = 4, NT = 4;
+    constexpr int PIECES = CAP / 8;
+    constexpr int SBUF = (CAP + 8) * 128, WSTG = BN * 128, REG = SBUF + WSTG;     // LDS: [strip 0][weights 0][strip 1][weights 1]
+    constexpr int SCRW = 64 * 64 * (int)sizeof(T);                                  // one wave's epilogue scratch
+    constexpr bool XPREF = NW * SCRW <= REG;      // the scratch fits the region the last K-step used: prefetch the next tile behind the last chunk
+    constexpr int ZW = CAP * 128 / SCRW;          // the wave whose scratch covers the region's zero row
+    static_assert(CAP % 8 == 0 && PIECES <= NTAPS * NW, "one strip piece per wave per K-step");
+    static_assert(!XPREF || (CAP * 128) % SCRW + 1024 <= SCRW, "zero row must lie inside one wave's scratch");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = tid >> 3, ch = tid & 7;
+    const int wm = wave & 3, wn = wave >> 2;
+    const int l16 = lane & 15, q = lane >> 4, l8 = lane >> 3, ls = lane & 7;
+    const int Cin = d.Cin, HoWo = d.Ho * d.Wo;
+    const int ncc = Cin / BK;
+    const int ntn = d.Nrows / BN, tpi = (HoWo + BM - 1) / BM;
+    const int ntiles = d.B * tpi * ntn, G = gridDim.x;
+
+    struct Tile { int img, p0, lo, NS, n_base, ti; bool g2, valid; };
+    auto get_tile = [&](int r) -> Tile {
+        Tile t{};
+        const int base = r * G, nwg = min(G, ntiles - base), o = blockIdx.x;
+        t.valid = nwg > 0 && o < nwg;
+        if (!t.valid) return t;
+        const int xcd = o & 7, qq = nwg >> 3, rr = nwg & 7;      // bijective XCD remap inside the round (T1)
+        const int bid = base + (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (o >> 3);
+        t.n_base = (bid % ntn) * BN;
+        const int mtile = bid / ntn;
+        t.img = mtile / tpi; t.ti = mtile - t.img * tpi; t.p0 = t.ti * BM;
+        const int p_last = min(t.p0 + BM, HoWo) - 1;
+        t.lo = max(0, t.p0 / d.Wo + d.dh_min);
+        const int hi = min(d.H - 1, p_last / d.Wo + d.dh_max);
+        t.NS = (hi - t.lo + 1) * d.W;
+        t.g2 = d.wp2 != nullptr && t.img >= d.group_images;
+        return t;
+    };
+
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, d.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wp1), 0, d.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(d.wp2 != nullptr ? d.wp2 : static_cast<const void*>(wp1)), 0, d.w_bytes, 0x00020000);
+
+    auto zero_rows = [&]() {                                  // rows CAP .. CAP+7 of both strip buffers
+        for (int i = tid; i < 2 * 64; i += 64 * NW)
+            *reinterpret_cast<u32x4_t*>(smem + (i >> 6) * REG + CAP * 128 + (i & 63) * 16) = u32x4_t{0u, 0u, 0u, 0u};
+    };
+    zero_rows();
+
+    // ---- strip DMA: piece j = strip rows 8j..8j+7; lane L -> row 8j + L/8, physical slot L%8 holding chunk (L%8 - (row & 6)) & 7
+    const unsigned svl = (unsigned)((l8 * Cin + ((ls - (l8 & 6)) & 7) * E) * (int)sizeof(T));
+    auto strip_base = [&](const Tile& t, int cc) -> unsigned {                 // scalar byte offset of (image, first strip row, chunk)
+        return (unsigned)__builtin_amdgcn_readfirstlane((((t.img * d.H + t.lo) * d.W) * Cin + cc * BK) * (int)sizeof(T));
+    };
+    auto issue_strip_piece = [&](int j, unsigned sbase, int NS, int region) {  // all arguments wave-uniform
+        const unsigned off = (8 * j + l8 < NS) ? svl + (unsigned)(8 * j * Cin * (int)sizeof(T)) : 0xFFFFFFFFu;
+        lds_ptr_t dst = (lds_ptr_t)smem + region * REG + j * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)dst, 16, (int)off, (int)sbase, 0, 0);
+    };
+    // ---- weight tile DMA: rows n_base + lr + 64 i, 16-byte chunk ch of physical slot ch ^ ((row >> 1) & 7) (rows are 16-aligned
+    //      per MFMA tile, the XOR form is conflict-free there)
+    unsigned wvl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wvl[i] = (unsigned)(((lr + 64 * i) * d.ldw + (ch ^ ((lr >> 1) & 7)) * E) * (int)sizeof(T));
+    auto w_base = [&](const Tile& t, int tp, int cc) -> unsigned {
+        const int te = __builtin_amdgcn_readfirstlane(d.tap[tp]);
+        return (unsigned)__builtin_amdgcn_readfirstlane((t.n_base * d.ldw + (te >> 16) * Cin + cc * BK) * (int)sizeof(T));
+    };
+    auto issue_w1 = [&](int i, bool g2, unsigned so, int region) {
+        lds_ptr_t dst = (lds_ptr_t)smem + region * REG + SBUF + wave * 1024 + i * 64 * 128;
+        if (g2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw2, (__attribute__((address_space(3))) void*)dst, 16, (int)wvl[i], (int)so, 0, 0);
+        else    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw1, (__attribute__((address_space(3))) void*)dst, 16, (int)wvl[i], (int)so, 0, 0);
+    };
+    auto issue_first = [&](const Tile& t, int region) {       // a tile's chunk-0 strip and first weight tile, all at once
+        const unsigned sb = strip_base(t, 0);
+        for (int j = wave; 8 * j < t.NS; j += NW) issue_strip_piece(j, sb, t.NS, region);
+        const unsigned so = w_base(t, 0, 0);
+        issue_w1(0, t.g2, so, region); issue_w1(1, t.g2, so, region);
+    };
+
+    Tile cur = get_tile(0);
+    if (!cur.valid) return;                                    // block-uniform (never taken: the grid is <= the tile count)
+    __syncthreads();                                           // zero rows written (no DMA in flight yet)
+    issue_first(cur, 0);
+
+    // ---- per-lane row table: LDS byte address (within a strip buffer, K half 0) of the B-operand row of output pixel
+    //      (tile row wm*64 + b*16 + l16) displaced by tap t; half 1 of the 128-byte row is address ^ 64.
+    //      Taps form a 3x3 grid: dh depends on t / 3 only, dw on t % 3 only (checked on the host).
+    unsigned short rt[NTAPS][MT];
+    int rt_ti = -1;
+    auto build_rt = [&](const Tile& tl) {
+        const bool refl = d.pad_mode == UIG_PAD_REFLECT;
+        const int ho0 = tl.p0 / d.Wo, rem0 = tl.p0 - ho0 * d.Wo;              // scalar
+#pragma unroll
+        for (int b = 0; b < MT; ++b) {
+            const int pr = rem0 + wm * WM + b * 16 + l16;                       // < Wo + 256
+            const int dho = (pr * d.wo_magic) >> 20;                            // pr / Wo (exact: host-checked range)
+            const int ho = ho0 + dho, wo = pr - dho * d.Wo;
+            const bool pv = tl.p0 + wm * WM + b * 16 + l16 < HoWo;
+            int hrow[3], wcol[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int hi_ = ho + (d.tap[3 * i] & 255) - 128;
+                const bool ok = refl | ((unsigned)hi_ < (unsigned)d.H);
+                hrow[i] = ok ? ((refl ? reflect_idx(hi_, d.H) : hi_) - tl.lo) * d.W : -65536;
+                const int wi_ = wo + ((d.tap[i] >> 8) & 255) - 128;
+                const bool okw = refl | ((unsigned)wi_ < (unsigned)d.W);
+                wcol[i] = okw ? (refl ? reflect_idx(wi_, d.W) : wi_) : -65536;
+            }
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) {
+                const int s0 = hrow[t / 3] + wcol[t % 3];
+                const int s = (pv & (s0 >= 0)) ? s0 : CAP;
+                rt[t][b] = (unsigned short)(s * 128 + (((q + (s & 6)) & 7) << 4));
+            }
+        }
+    };
+
+    const int wswz = (l16 >> 1) & 7;
+    int par = 0;                                               // region holding chunk 0 of the current tile
+    for (int r = 0;; ++r) {
+        const Tile nxt = get_tile(r + 1);
+        if (cur.ti != rt_ti) { build_rt(cur); rt_ti = cur.ti; }
+        const float* bias = cur.g2 ? d.bias2 : bias1;
+
+        f32x4_t acc[NT][MT];
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int b = 0; b < MT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+        for (int cc = 0; cc < ncc; ++cc) {
+            const int pc = par ^ (cc & 1);                     // region of this chunk's strip; weight stage of step t: pc ^ (t & 1)
+            const unsigned char* sx = smem + pc * REG;
+            const bool last_cc = cc + 1 == ncc;
+            const bool pre_next = XPREF && last_cc && nxt.valid;
+            // next strip chunk streamed into the other region behind this chunk's MFMAs: chunk cc+1 of this tile, or chunk 0 of the next
+            const bool s_on = !last_cc || pre_next;
+            const unsigned s_base = !last_cc ? strip_base(cur, cc + 1) : strip_base(nxt, 0);
+            const int s_NS = !last_cc ? cur.NS : nxt.NS;
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) {                   // fully unrolled: the row table is statically indexed
+                // this wave's DMAs (weight tile of this step, strip pieces) have landed and its fragment reads of the previous
+                // step are complete (the DMAs issued below overwrite that step's weight stage) ...
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                   // ... and everyone else's
+                const bool last_t = t + 1 == NTAPS;
+                const bool w_on = !(last_t && last_cc) || pre_next;
+                const bool w_g2 = (last_t && last_cc) ? nxt.g2 : cur.g2;
+                const unsigned w_so = !last_t ? w_base(cur, t + 1, cc) : (!last_cc ? w_base(cur, 0, cc + 1) : w_base(nxt, 0, 0));
+                const int w_reg = pc ^ ((t + 1) & 1);
+                const int slot = t * NW + wave;
+                const bool p_on = s_on && slot < PIECES && 8 * slot < s_NS;
+                auto dma = [&](int which) {                     // 0 / 1: the two halves of the next weight tile, 2: this wave's strip piece
+                    if (which < 2) { if (w_on) issue_w1(which, w_g2, w_so, w_reg); }
+                    else if (p_on) issue_strip_piece(slot, s_base, s_NS, pc ^ 1);
+                };
+                if constexpr (DM == 0) { dma(0); dma(1); dma(2); }
+                const unsigned char* sw = smem + (pc ^ (t & 1)) * REG + SBUF + (wn * WN + l16) * 128;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    u32x4_t xf[MT], wf[NT];
+#pragma unroll
+                    for (int b = 0; b < MT; ++b) xf[b] = *reinterpret_cast<const u32x4_t*>(sx + ((unsigned)rt[t][b] ^ (unsigned)(h << 6)));
+                    const int co = ((q + 4 * h) ^ wswz) << 4;
+#pragma unroll
+                    for (int a = 0; a < NT; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(sw + a * 16 * 128 + co);
+#pragma unroll
+                    for (int a = 0; a < NT; ++a) {
+#pragma unroll
+                        for (int b = 0; b < MT; ++b) MmaS<T>::run(wf[a], xf[b], acc[a][b]);
+                        if constexpr (DM == 1) {                // one DMA piece behind every 4th MFMA group of the step
+                            if (h == 0 && a == 0) { __builtin_amdgcn_sched_barrier(0); dma(0); __builtin_amdgcn_sched_barrier(0); }
+                            if (h == 0 && a == 2) { __builtin_amdgcn_sched_barrier(0); dma(1); __builtin_amdgcn_sched_barrier(0); }
+                            if (h == 1 && a == 0) { __builtin_amdgcn_sched_barrier(0); dma(2); __builtin_amdgcn_sched_barrier(0); }
+                        }
+                    }
+                }
+            }
+        }
+        const int pl = par ^ ((ncc - 1) & 1);                  // region of the last chunk == weight stage of the last step (9 taps: odd)
+
+        // ---- epilogue: scratch = the region the last K-step has just finished with (the prefetch went to the other one)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // every wave is done reading region pl (raw: the prefetch DMAs stay in flight)
+        unsigned char* scratch = smem + (XPREF ? pl * REG : 0) + wave * SCRW;
+        strip_epilogue<T, MT, NT, WM, WN>(acc, scratch, d, y, bias, cur.img, cur.p0, wm, wn, cur.n_base, lane);
+        if (!nxt.valid) break;
+        if constexpr (XPREF) {
+            // the scratch covered region pl's zero row: its owner restores it (read again from the next tile's chunk 1 on,
+            // many barriers from here)
+            if (wave == ZW) *reinterpret_cast<u32x4_t*>(smem + pl * REG + CAP * 128 + lane * 16) = u32x4_t{0u, 0u, 0u, 0u};
+            par = pl ^ 1;
+        } else {
+            // fp32 tiles: the scratch spans both regions, so the next tile starts like the first one
+            __syncthreads();
+            zero_rows();
+            par = 0;
+            issue_first(nxt, 0);
+        }
+        cur = nxt;
+    }
+}
+
+template __global__ void conv_strip_pk_kernel<bf16_t, 448, 0>(const bf16_t*, const bf16_t*, const float*, bf16_t*, const StripDesc);
+template __global__ void conv_strip_pk_kernel<bf16_t, 448, 1>(const bf16_t*, const bf16_t*, const float*, bf16_t*, const StripDesc);
+template __global__ void conv_strip_pk_kernel<float, 448, 1>(const float*, const float*, const float*, float*, const StripDesc);
+
+static int g_pk_dm = 1;        // tuning hook: DMA issue placement of the bf16 kernel (0 = top of the step, 1 = spread between MFMA groups)
+static int g_pk_grid = 0;      // tuning hook: persistent grid size (0 = one block per CU)
+extern "C" void uig_debug_set_strip_pk(int dm, int grid) { g_pk_dm = dm; g_pk_grid = grid; }
+
+static int device_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
+
+template <typename T, int CAP, int DM>
+static int launch_pk(const void* x, const void* wp, const float* bias, void* y, const StripDesc& d, int ntiles, hipStream_t s) {
+    const size_t smem = 2 * ((size_t)(CAP + 8) * 128 + 128 * 128);
+    auto kern = conv_strip_pk_kernel<T, CAP, DM>;
+    static SmemAttrOnce attr_once;
+    {
+        hipError_t e = attr_once.ensure(reinterpret_cast<const void*>(kern), smem);
+        if (e != hipSuccess) return uig_set_error((int)e, "conv_strip_pk: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    }
+    const int grid = std::min(ntiles, g_pk_grid > 0 ? g_pk_grid : device_cus());
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, (const T*)x, (const T*)wp, bias, (T*)y, d);
+    UIG_LAUNCH_CHECK("uig_conv_gather(strip, persistent)");
+    return 0;
+}
+
+// 1 if the persistent kernel can take this 256x128-tile launch (d filled by uig_try_conv_strip): taps must form a 3x3 grid
+// (dh a function of t / 3, dw of t % 3) and the in-tile division by Wo must be exact in 20-bit fixed point.
+bool uig_strip_pk_ok(const StripDesc& d, int need256) {
+    if (need256 > 448 || d.Wo > 512) return false;
+    for (int t = 0; t < 9; ++t)
+        if ((d.tap[t] & 255) != (d.tap[3 * (t / 3)] & 255) || ((d.tap[t] >> 8) & 255) != ((d.tap[t % 3] >> 8) & 255)) return false;
+    return true;
+}
+
+int uig_launch_strip_pk(const void* x, const void* wp, const float* bias, void* y, StripDesc d, int dtype, hipStream_t s) {
+    d.wo_magic = ((1 << 20) + d.Wo - 1) / d.Wo;             // (pr * magic) >> 20 == pr / Wo for pr < Wo + 256 <= 768 (pr * (magic * Wo - 2^20) < 2^20)
+    const int tpi = (d.Ho * d.Wo + 255) / 256;
+    const int ntiles = d.B * tpi * (d.Nrows / 128);
+    if (dtype == UIG_BF16)
+        return g_pk_dm == 0 ? launch_pk<bf16_t, 448, 0>(x, wp, bias, y, d, ntiles, s) : launch_pk<bf16_t, 448, 1>(x, wp, bias, y, d, ntiles, s);
+    return launch_pk<float, 448, 1>(x, wp, bias, y, d, ntiles, s);
+}

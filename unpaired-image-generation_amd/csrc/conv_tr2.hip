@@ -217,12 +217,12 @@ int uig_try_conv_tr2(const void* x, const void* wp, const float* bias, const voi
     // the wave roles assume 1 / 2 / 2 / 4 taps for phases 0..3
     if (d.ph_tap0[1] - d.ph_tap0[0] != 1 || d.ph_tap0[2] - d.ph_tap0[1] != 2 || d.ph_tap0[3] - d.ph_tap0[2] != 2) return 0;
     d.wp2 = wp2; d.bias2 = bias2; d.group_images = group_images; d.in_partial = in_partial;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tr2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TR_SMEM);
+    static SmemAttrOnce attr_once;
+    {
+        hipError_t e = attr_once.ensure(reinterpret_cast<const void*>(conv_tr2_kernel), (size_t)TR_SMEM);
         if (e != hipSuccess) { *rc_out = uig_set_error((int)e, "conv_tr2: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return 1; }
-        attr_done = true;
     }
+    uig_note_conv_kernel(UIG_K_TR2);
     hipLaunchKernelGGL(conv_tr2_kernel, dim3(B * (H / TI) * (Nrows / 64)), dim3(512), TR_SMEM, s,
                        (const bf16_t*)x, (const bf16_t*)wp, bias, (bf16_t*)y, d);
     hipError_t e = hipGetLastError();

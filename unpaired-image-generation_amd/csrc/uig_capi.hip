@@ -15,6 +15,12 @@ int uig_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* uig_last_error(void) { return g_err; }
+
+// which kernel family the calling thread's last uig_conv_gather* launch ran on (UIG_K_*): lets a parity test assert that it
+// covers the kernel it means to cover instead of a fallback
+static thread_local int g_last_conv_kernel = 0;
+void uig_note_conv_kernel(int id) { g_last_conv_kernel = id; }
+extern "C" int uig_debug_last_conv_kernel(void) { return g_last_conv_kernel; }
 extern "C" const char* uig_version(void) { return "uig 0.1 (gfx950, hipcc, wave64 MFMA 16x16)"; }
 
 extern "C" int uig_device_ok(void) {

@@ -84,13 +84,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 // channels; receives (sum, sum of squares) over the first nvalid pixel rows of the tile AS STORED (rounded to T), so the
 // separate statistics pass of the following InstanceNorm disappears.
 struct NoRowAdd { __device__ __forceinline__ u32x4_t operator()(int, int, const u32x4_t& v, int) const { return v; } };
+struct NoMidHook { __device__ __forceinline__ void operator()() const {} };
 // row_add(r, c, chunk, i) may modify the 16-byte chunk c of tile row r just before it is stored (border terms of the
 // reflection-pad input gradient); i is the (compile-time, after unrolling) index of the store instruction: r = r0 + RPI*i.
-template <typename T, int MT, int NT, typename RowPtr, typename RowAdd = NoRowAdd>
+// mid() runs between the tile's LDS writes (the accumulators are dead from there on) and the row reads: a place to issue
+// loads whose destination registers may then reuse the accumulators'.
+template <typename T, int MT, int NT, typename RowPtr, typename RowAdd = NoRowAdd, typename MidHook = NoMidHook>
 __device__ __forceinline__ void store_tile_via_lds(const f32x4_t (&acc)[NT][MT], unsigned char* scratch, int lane,
                                                    const float* bias4 /* NT*4 bias values of this lane, or nullptr */,
                                                    int act, float slope, RowPtr row_ptr, float* stat_out = nullptr,
-                                                   int nvalid = 64, RowAdd row_add = RowAdd()) {
+                                                   int nvalid = 64, RowAdd row_add = RowAdd(), MidHook mid = MidHook()) {
     static_assert(MT == 4 && NT == 4, "64 x 64 wave tile");
     constexpr int ROWB = 64 * (int)sizeof(T);          // 128 (bf16) / 256 (f32) bytes per pixel row
     constexpr int NCH = ROWB / 16;                     // 16-byte chunks per row
@@ -118,6 +121,7 @@ __device__ __forceinline__ void store_tile_via_lds(const f32x4_t (&acc)[NT][MT],
     // The tile is written as 8-byte / f32x4 vectors and read back as u32x4: different vector types, which type-based alias
     // analysis may treat as non-aliasing (seen in conv_cin8.hip: reads scheduled above the writes).  Compiler barrier.
     asm volatile("" ::: "memory");
+    mid();
     // the scratch is private to the wave: only its own LDS writes must have landed (the compiler inserts lgkmcnt waits)
     constexpr int RPI = 64 / NCH;                      // rows per store instruction (8 for bf16, 4 for f32)
     const int c = lane % NCH, r0 = lane / NCH;
@@ -141,5 +145,20 @@ __device__ __forceinline__ void store_tile_via_lds(const f32x4_t (&acc)[NT][MT],
 
 // host-side error plumbing (defined in uig_capi.hip)
 int uig_set_error(int code, const char* fmt, ...);
+void uig_note_conv_kernel(int id);      // UIG_K_* of include/uig.h, read back by uig_debug_last_conv_kernel()
+
+// One-time raise of a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize), callable from any host
+// thread: the attribute call is idempotent, the flag is published (release) only after it succeeded, and a function-local
+// `static SmemAttrOnce` is initialised thread-safely by the language.  One device per process (the DP model of this library).
+#include <atomic>
+struct SmemAttrOnce {
+    std::atomic<bool> done{false};
+    hipError_t ensure(const void* fn, size_t bytes) {
+        if (done.load(std::memory_order_acquire)) return hipSuccess;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess) done.store(true, std::memory_order_release);
+        return e;
+    }
+};
 #define UIG_CHECK_ARG(cond, ...) do { if (!(cond)) return uig_set_error(-1, __VA_ARGS__); } while (0)
 #define UIG_LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return uig_set_error((int)e_, "%s: launch failed: %s", name, hipGetErrorString(e_)); } while (0)

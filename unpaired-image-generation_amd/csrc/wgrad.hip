@@ -326,11 +326,10 @@ static int launch_wgrad(const void* P, const void* Q, float* ws, const WgradDesc
     constexpr int PROW = BN * (int)sizeof(T) + WgTraits<T>::PAD, QROW = 128 * (int)sizeof(T) + WgTraits<T>::PAD;
     const size_t smem = 2 * (size_t)(sizeof(T) == 2 ? 64 : 32) * (size_t)(PROW + QROW);
     auto kern = wgrad_kernel<T, BN, FASTROW>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    static SmemAttrOnce attr_once;
+    {
+        hipError_t e = attr_once.ensure(reinterpret_cast<const void*>(kern), (size_t)(int)smem);
         if (e != hipSuccess) return uig_set_error((int)e, "wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_done = true;
     }
     const int ntn = (d.Np + BN - 1) / BN, ntc = (d.ncols + 127) / 128;
     hipLaunchKernelGGL(kern, dim3(ntn * ntc, splits * (d.group_M > 0 ? 2 : 1)), dim3(BN >= 256 ? 512 : 256), smem, s, (const T*)P, (const T*)Q, ws, d);

@@ -192,11 +192,10 @@ int uig_launch_wgrad_head(const void* P, const void* Q, float* ws, int B, int H,
     d.splits = splits; d.group_rows = group_images * H;
     d.p_bytes = (unsigned)((long)B * H * W * Np * 2); d.q_bytes = (unsigned)((long)B * H * W * WH_CI * 2);
     const size_t smem = (size_t)WH_NST * WH_STAGE + WH_S;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_head7_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    static SmemAttrOnce attr_once;
+    {
+        hipError_t e = attr_once.ensure(reinterpret_cast<const void*>(wgrad_head7_kernel), (size_t)(int)smem);
         if (e != hipSuccess) return uig_set_error((int)e, "wgrad(head): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_done = true;
     }
     hipLaunchKernelGGL(wgrad_head7_kernel, dim3(7 * splits * (group_images > 0 ? 2 : 1)), dim3(256), smem, s, (const bf16_t*)P,
                        (const bf16_t*)Q, ws, d);

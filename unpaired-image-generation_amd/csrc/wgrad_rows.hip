@@ -278,11 +278,10 @@ int uig_launch_wgrad_rows(const void* P, const void* Q, float* ws, int B, int H,
     d.ntc = Cq / 128; d.ntiles = uig_wgrad_rows_tiles(Np, Cq); d.splits = splits;
     d.p_bytes = (unsigned)((long)B * H * WR_W * Np * 2); d.q_bytes = (unsigned)((long)B * H * WR_W * Cq * 2);
     const size_t smem = (size_t)WR_NST * WR_STAGE;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_rows3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    static SmemAttrOnce attr_once;
+    {
+        hipError_t e = attr_once.ensure(reinterpret_cast<const void*>(wgrad_rows3_kernel), (size_t)(int)smem);
         if (e != hipSuccess) return uig_set_error((int)e, "wgrad(rows): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_done = true;
     }
     hipLaunchKernelGGL(wgrad_rows3_kernel, dim3(d.ntiles * splits * (group_images > 0 ? 2 : 1)), dim3(512), smem, s, (const bf16_t*)P, (const bf16_t*)Q, ws, d);
     UIG_LAUNCH_CHECK("uig_wgrad_partial(rows)");

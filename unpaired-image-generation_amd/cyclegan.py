@@ -196,7 +196,7 @@ class CycleGAN:
         for name, grp in (("G", self.grp_G), ("D", self.grp_D)):
             step = grp.step
             st = getattr(grp, "state16", None)
-            if st is not None:                              # graph mode keeps the authoritative counter on the device
+            if st is not None and self.graph_active:        # graph mode keeps the authoritative counter on the device
                 step = int(st[0].item())
             sd["opt_" + name] = {"m": grp.m.clone(), "v": grp.v.clone(), "step": step}
         return sd
@@ -246,6 +246,34 @@ class CycleGAN:
         l_D_A = ld[0][0] + ld[0][1]
         l_D_B = ld[1][0] + ld[1][1]
         return torch.cat(lg + [l_D_A, l_D_B])
+
+    @property
+    def graph_active(self) -> bool:
+        """True while train_step really replays captured HIP graphs (False before the first step, in eager mode, and after a
+        refused capture made graph_train_step fall back to eager launches)."""
+        return bool(self.use_graph and self._graphs is not None)
+
+    def close(self):
+        """Ordered teardown of everything this model holds on the device BEFORE the caller destroys the process group or the
+        interpreter exits: drain the device, then drop the captured graphs (their executables and private memory pool), the
+        weight packers' descriptor tables and the side streams, and drain again.  Left to interpreter shutdown these are
+        finalized in arbitrary order relative to RCCL's communicator and torch's allocator, which round 1 saw abort at exit.
+        The model is unusable for graph replay afterwards (a later train_step would capture again)."""
+        import gc
+        torch.cuda.synchronize(self.device)
+        st, self._graphs = self._graphs, None
+        if st is not None:
+            for name in ("g4", "g3", "g2", "g1"):
+                if hasattr(st, name):
+                    delattr(st, name)
+            st.__dict__.clear()
+        del st
+        self.__dict__.pop("_packers", None)
+        self.__dict__.pop("_upd_stream", None)
+        self.xchg.close()
+        ops.release_side_streams(self.device)
+        gc.collect()
+        torch.cuda.synchronize(self.device)
 
     def to_phys(self, x):
         """logical (B,3,H,W) -> physical (B,H,W,8) in the compute dtype; a tensor that already is physical (as the

@@ -51,10 +51,16 @@ class GradExchange:
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.force = force and dist.is_available() and dist.is_initialized()   # exercise the collective even at world 1
         self._stream = None
+        self.n_started = 0                                  # collectives really issued (tests assert the exchange path ran)
+
+    def close(self):
+        """drop the communication stream (after the device has been drained by the owner)"""
+        self._stream = None
 
     def start(self, flat: torch.Tensor):
         if self.world <= 1 and not self.force:
             return None
+        self.n_started += 1
         if flat.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=flat.device)

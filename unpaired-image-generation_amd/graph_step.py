@@ -82,6 +82,9 @@ def graph_train_step(model, real_A, real_B):
             print(f"[uig] HIP-graph capture failed ({e}); continuing in eager mode", file=sys.stderr, flush=True)
             torch.cuda.synchronize(model.device)
             model._graphs, model.use_graph = None, False
+            for grp in (model.grp_G, model.grp_D):          # the eager Adam counts steps on the host: drop the device records
+                if hasattr(grp, "state16"):
+                    del grp.state16
             return model._step_eager(model.to_phys(real_A), model.to_phys(real_B))
     st.real_A.copy_(real_A, non_blocking=True)
     st.real_B.copy_(real_B, non_blocking=True)

@@ -14,6 +14,7 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 GATHER_DIRECT, GATHER_TRANSPOSED = 0, 1
 PACK_ROW_DIM0, PACK_ROW_DIM1 = 0, 1
+K_NONE, K_IGEMM, K_STRIP128, K_STRIP256, K_STRIP_PK, K_ROWSTRIP, K_HEADROW, K_GEMV, K_CIN8, K_TR2 = range(10)   # uig_debug_last_conv_kernel()
 
 _vp, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 
@@ -22,8 +23,10 @@ SIGNATURES = {
     "uig_version": (C.c_char_p, []),
     "uig_last_error": (C.c_char_p, []),
     "uig_device_ok": (_i, []),
+    "uig_debug_last_conv_kernel": (_i, []),
     "uig_debug_set_tile": (None, [_i]),
     "uig_debug_set_strip": (None, [_i]),
+    "uig_debug_set_strip_pk": (None, [_i, _i]),
     "uig_debug_set_rowstrip": (None, [_i]),
     "uig_debug_set_strip_stamps": (None, [_vp]),
     "uig_conv_gather": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_i, _f, _i, _vp]),
@@ -31,6 +34,7 @@ SIGNATURES = {
     "uig_conv_gather_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp] + [_i] * 15 + [_i, _f, _i, _vp]),
     "uig_reflect3x3_dgrad_border": (_i, [_vp, _vp, _vp, _i, _vp] + [_i] * 7 + [_vp]),
     "uig_conv_strip_applicable": (_i, [_i] * 10),
+    "uig_conv_strip_tile": (_i, [_i] * 10),
     "uig_wgrad_workspace_bytes": (_sz, [_i] * 5),
     "uig_wgrad_tile_rows": (_i, [_i, _i, _i]),
     "uig_debug_set_wgrad_wide": (None, [_i]),

@@ -32,6 +32,11 @@ def _side_stream(device) -> torch.cuda.Stream:
     return st
 
 
+def release_side_streams(device) -> None:
+    """forget the parameter-gradient side stream of `device` (CycleGAN.close(): ordered teardown)"""
+    _SIDE_STREAMS.pop(torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), None)
+
+
 class deferred_param_grads:
     """Context manager for a backward region whose parameter gradients are accumulated in place (trainer-owned flat
     gradient buffers): inside it the conv backward does not join its side stream after every layer; on exit the main
