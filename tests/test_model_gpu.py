@@ -357,12 +357,14 @@ def test_pool_schedule_resume_vs_oracle_fp32(tmp_path):
     _load_oracle_weights(m, o)
 
     def check(step, lo, lm, what):
-        tol = 2e-4 if step == 0 else 2e-3
+        tol = (2e-4, 2e-3, 2e-2, 4e-2)[step]
         for k in lo:
             assert abs(lo[k] - lm[k]) <= tol * max(1.0, abs(lo[k])), (what, step, k, lo[k], lm[k])
 
     mr = None
+    upd = {}
     for step, (rA, rB) in enumerate(batches):
+        w_hip, w_or = m.grp_D.flat.clone(), torch.cat([p.detach().reshape(-1) for n in (o.D_A, o.D_B) for p in n.parameters()])
         if step == 2:
             o.set_epoch(150, 100, 100); m.set_epoch(150, 100, 100)            # LR x (1 - 50/101)
         if step == 3:                                                         # resume from the checkpoint written after step 2
@@ -376,43 +378,37 @@ def test_pool_schedule_resume_vs_oracle_fp32(tmp_path):
             check(step, lo, mr.train_step(rA.cuda(), rB.cuda()), "resumed")
         if step == 2:
             m.save(str(tmp_path / "ckpt.pt"))
+        w_or2 = torch.cat([p.detach().reshape(-1) for n in (o.D_A, o.D_B) for p in n.parameters()])
+        upd[step] = (float((m.grp_D.flat - w_hip).abs().sum()), float((w_or2 - w_or).abs().sum()))
+    # the decayed steps move the discriminators' weights by the same total amount as the oracle's LambdaLR'd Adam does
+    # (scale 1 - 50/101: ignoring it would double the update), and by visibly less than the undecayed step before
+    for step in (1, 2, 3):
+        assert abs(upd[step][0] / upd[step][1] - 1.0) < 0.05, (step, upd[step])
+    assert upd[2][0] < 0.75 * upd[1][0]
     assert m.pool_B.n == 3 and len(o.pool_B.images) == 3
-    # the discriminators really saw pooled (older) fakes: the pools' contents agree with the oracle's image for image
+    # the discriminators really saw pooled (older) fakes: the pools' contents agree with the oracle's slot for slot (the same
+    # image of the same step in the same slot: fakes of different steps / slots differ by O(0.5); the same fake differs by the
+    # accumulated weight drift of the steps before it, a few 1e-2 at most)
     for mine, theirs in ((m.pool_B, o.pool_B), (m.pool_A, o.pool_A)):
         for j in range(3):
-            assert float((u.ops.from_nhwc(mine.buf[j:j + 1], 3).cpu() - theirs.images[j]).abs().max()) < 5e-2
-    # post-schedule Adam: weights moved by <= lr * scale in the decayed steps
+            dlt = (u.ops.from_nhwc(mine.buf[j:j + 1], 3).cpu() - theirs.images[j]).abs()
+            assert float(dlt.max()) < 0.25 and float(dlt.mean()) < 0.03, (j, float(dlt.max()), float(dlt.mean()))
     m.close(); mr.close()
 
 
 def test_graph_step_with_rccl_exchange_world1_and_close():
-    """Guards two aborts seen in round 1 (graph_step.py: capture with a live process group; process exit with graphs + RCCL
-    alive): one process, init_process_group('nccl', world_size=1), CycleGAN(use_graph=True, force_exchange=True) so that the
-    RCCL all-reduces really run between the graph replays; 3 steps bitwise equal to the model without exchange (a 1-rank sum
-    is the identity); then the ordered teardown: CycleGAN.close() before destroy_process_group()."""
-    import socket
-    import torch.distributed as dist
-    import unpaired_image_generation_amd as u
-    if dist.is_initialized():
-        pytest.skip("a process group is already alive in this process")
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        torch.manual_seed(21)
-        rA, rB = (torch.rand(2, 3, 64, 64, device="cuda") * 2 - 1 for _ in range(2))
-        torch.manual_seed(5)
-        m0 = u.CycleGAN(n_blocks=6, dtype=torch.bfloat16, use_graph=True)
-        m1 = u.CycleGAN(n_blocks=6, dtype=torch.bfloat16, use_graph=True, force_exchange=True)
-        m1.load_state_dicts(*[n.state_dict() for n in m0.nets()])
-        assert m1.xchg.force and m0.xchg.world == 1
-        for step in range(3):
-            l0, l1 = m0.train_step(rA, rB), m1.train_step(rA, rB)
-            assert m1.graph_active and m0.graph_active
-            assert l0 == l1, (step, l0, l1)
-        assert torch.equal(m0.grp_G.flat, m1.grp_G.flat) and torch.equal(m0.grp_D.flat, m1.grp_D.flat)
-        assert m1.xchg.n_started >= 6          # two all-reduces per step really went through RCCL
-        m1.close(); m0.close()
-        assert m1._graphs is None
-    finally:
-        dist.destroy_process_group()
+    """Guards two aborts seen in round 1 (graph capture with a live process group; process exit with graphs + RCCL alive).
+    One worker process = one rank, as in production (the process group lives as long as the process):
+    init_process_group('nccl', world_size=1), CycleGAN(use_graph=True, force_exchange=True) so that the RCCL all-reduces
+    really run between the graph replays; 3 steps bitwise equal to the model without exchange (a 1-rank sum is the identity);
+    then the ordered teardown - CycleGAN.close(), destroy_process_group() - and a NORMAL interpreter exit whose status is
+    checked here (tests/_rccl_world1_worker.py).  A separate process because a process group created and destroyed in the
+    middle of this pytest session made the first graph replay of a LATER test crash inside the HIP runtime (seen twice,
+    deterministic; never in a process whose group lives until exit)."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rccl_world1_worker.py")
+    r = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-2000:]); print(r.stderr[-3000:])
+    assert r.returncode == 0, f"worker exit status {r.returncode}"
+    assert "RCCL_WORLD1_OK" in r.stdout

@@ -36,26 +36,33 @@ template <> struct MmaS<float> {
 };
 
 
-// Epilogue of one BM x BN strip tile, shared by conv_strip.hip and conv_strip_pk.hip: bias (+ activation), optional reflection-border /
+// Accumulator initialisation of a strip tile: the bias rides in the accumulators from the start (acc = bias + sum of
+// products, one fp32 rounding order for every strip kernel), so the epilogue carries no bias registers: its 16 scalar loads
+// per lane were the first thing the register allocator spilled, one `s_waitcnt vmcnt(0)` each, in the persistent kernel.
+template <int MT, int NT, int WN>
+__device__ __forceinline__ void strip_init_acc(f32x4_t (&acc)[NT][MT], const float* __restrict__ bias, int Nrows, int n_base, int wn, int lane) {
+    const int q = lane >> 4;
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+        const int n = n_base + wn * WN + a * 16 + 4 * q;         // Nrows is a multiple of 128 for every strip launch: n + 3 < Nrows
+        const f32x4_t bv = (bias != nullptr && n < Nrows) ? *reinterpret_cast<const f32x4_t*>(bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] = bv;
+    }
+}
+
+// Epilogue of one BM x BN strip tile, shared by conv_strip.hip and conv_strip_pk.hip: activation, optional reflection-border /
 // residual adds, optional InstanceNorm partial statistics; full-row stores through this wave's 64x64 LDS scratch when its 64
-// channels are all stored, else direct 8/16-byte stores.  The caller has made sure (barrier) that `scratch` is free.
+// channels are all stored, else direct 8/16-byte stores.  The bias is already in the accumulators (strip_init_acc).
+// The caller has made sure (barrier) that `scratch` is free.
 template <typename T, int MT, int NT, int WM, int WN>
 __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], unsigned char* scratch, const StripDesc& d, T* __restrict__ y,
-                                               const float* __restrict__ bias, int img, int p0, int wm, int wn, int n_base, int lane) {
+                                               int img, int p0, int wm, int wn, int n_base, int lane) {
     const int HoWo = d.Ho * d.Wo;
     const int l16 = lane & 15, q = lane >> 4;
-    // ---- epilogue: full-row stores through LDS when this wave's 64 channels are all stored, else direct 8/16-byte stores
     const bool vec_ok = ((d.Nstore & 3) == 0) && ((d.ldc & 3) == 0);
     const int nw0 = n_base + wn * WN;
     if (MT == 4 && NT == 4 && vec_ok && nw0 + 64 <= d.Nstore && (d.ldc * (int)sizeof(T)) % 16 == 0) {      // wave-uniform choice
-        float b4[NT * 4];
-#pragma unroll
-        for (int a = 0; a < NT; ++a)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int n = nw0 + a * 16 + 4 * q + e;
-                b4[a * 4 + e] = (bias != nullptr && n < d.Nrows) ? bias[n] : 0.f;
-            }
         const int pw = p0 + wm * WM;
         T* ybase = y + (long)img * HoWo * d.ldc + nw0;
         float* so = nullptr;
@@ -63,16 +70,19 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
             so = d.in_partial + (((long)img * ((HoWo + 63) / 64) + pw / 64) * d.Nstore + nw0) * 2;
         auto rowp = [&](int r) -> T* { const int p = pw + r; return p < HoWo ? ybase + (long)p * d.ldc : nullptr; };
         if (d.border_add == nullptr && d.res_add == nullptr) {
-            store_tile_via_lds<T, MT, NT>(acc, scratch, lane, b4, d.act, d.slope, rowp, so, min(64, HoWo - pw));
+            store_tile_via_lds<T, MT, NT>(acc, scratch, lane, nullptr, d.act, d.slope, rowp, so, min(64, HoWo - pw));
         } else {
             // reflection-pad dgrad: add the mirrored-border terms (phases T,B,L,R,TL,TR,BL,BR of the compact border buffer)
             constexpr int E = ElemTraits<T>::E;
             const int S = d.Ho;                                   // square map
             const T* bimg = static_cast<const T*>(d.border_add) + (long)img * 8 * S * d.ldc + nw0;
             if constexpr (sizeof(T) == 2) {
-                // bf16: all border chunks of this lane's 8 store rows are fetched NOW (3 range-checked buffer loads per row:
-                // line term, column term, corner; an out-of-range offset returns zeros, so no branches), and their latency
-                // hides behind the LDS transposition.  Loading them inside the store loop cost the kernel 9-20 us.
+                // bf16: the border chunk and the residual chunk of this lane's 8 store rows are fetched NOW (range-checked buffer
+                // loads: an out-of-range offset returns zeros, so no branches), and their latency hides behind the LDS
+                // transposition; loading them inside the store loop cost the kernel 9-20 us.  A pixel has at most ONE border
+                // term (its line's or its column's) except the four pixels (1|S-2, 1|S-2) of an image, which also take the
+                // column and corner terms: those are loaded in the store loop by the lanes concerned (2 of 128 wave tiles of a
+                // 64x64 map).  2 prefetched chunks per row instead of 4: 64 registers instead of 128 at the epilogue's peak.
                 const bool hasb = d.border_add != nullptr, hasr = d.res_add != nullptr;
                 const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<void*>(hasb ? d.border_add : d.res_add), 0, hasb ? (unsigned)((long)d.B * 8 * S * d.ldc * (int)sizeof(T)) : 0u, 0x00020000);
@@ -80,45 +90,49 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
                     const_cast<void*>(hasr ? d.res_add : d.border_add), 0, hasr ? (unsigned)((long)d.B * HoWo * d.ldc * (int)sizeof(T)) : 0u, 0x00020000);
                 constexpr int NI = 8;                                  // 64 rows / 8 rows per store instruction
                 const int c = lane % 8, r0 = lane / 8;
-                u32x4_t pre[NI][4];                                    // line term, column term, corner, residual tensor
-                // rows i < NI/2 are fetched before the transposition (while the accumulators are live), rows i >= NI/2 in its
-                // mid hook, when the accumulators are dead: 64 fewer live registers at the peak, and the second half's latency
-                // hides behind the first half's row reads and stores
-                auto fetch = [&](int i) {
+                auto boff = [&](int phase, int pos) -> int {
+                    return (int)(((((long)img * 8 + phase) * S + pos) * d.ldc + nw0 + c * E) * (long)sizeof(T));
+                };
+                u32x4_t pre[NI][2];                                    // border term (line or column), residual tensor
+                unsigned both = 0;                                     // bit i: row i is one of the image's four double-border pixels
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
                     const int p = pw + r0 + 8 * i;
                     const int h = p / d.Wo, w = p - h * d.Wo;
                     const bool ok = p < HoWo;
                     const bool okb = ok & hasb;
                     const bool rt_ = okb & (h == 1), rb_ = okb & (h == S - 2), cl_ = okb & (w == 1), cr_ = okb & (w == S - 2);
-                    auto off = [&](bool on, int phase, int pos) -> int {
-                        return on ? (int)(((((long)img * 8 + phase) * S + pos) * d.ldc + nw0 + c * E) * (long)sizeof(T)) : -1;
-                    };
-                    pre[i][0] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsb, off(rt_ | rb_, rt_ ? 0 : 1, w), 0, 0));
-                    pre[i][1] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsb, off(cl_ | cr_, cl_ ? 2 : 3, h), 0, 0));
-                    pre[i][2] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
-                        rsb, off((rt_ | rb_) & (cl_ | cr_), (rt_ ? 4 : 6) + (cr_ ? 1 : 0), 0), 0, 0));
-                    pre[i][3] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                    const int o0 = (rt_ | rb_) ? boff(rt_ ? 0 : 1, w) : ((cl_ | cr_) ? boff(cl_ ? 2 : 3, h) : -1);
+                    pre[i][0] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsb, o0, 0, 0));
+                    pre[i][1] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
                         rsr, ok ? (int)((((long)img * HoWo + p) * d.ldc + nw0 + c * E) * (long)sizeof(T)) : -1, 0, 0));
-                };
-#pragma unroll
-                for (int i = 0; i < NI / 2; ++i) fetch(i);
-                auto mid = [&]() {
-#pragma unroll
-                    for (int i = NI / 2; i < NI; ++i) fetch(i);
-                };
-                auto add = [&](int, int, const u32x4_t& v, int i) -> u32x4_t {
+                    both |= (((rt_ | rb_) & (cl_ | cr_)) ? 1u : 0u) << i;
+                }
+                auto add = [&](int r, int, const u32x4_t& v, int i) -> u32x4_t {
                     float f[E], g[E];
                     chunk_to_f32<T>(v, f);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < 2; ++k) {
                         chunk_to_f32<T>(pre[i][k], g);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) f[e] += g[e];
+                    }
+                    if ((both >> i) & 1u) {                            // rare: column term + corner term of a double-border pixel
+                        const int p = pw + r;
+                        const int h = p / d.Wo, w = p - h * d.Wo;
+                        const u32x4_t cv = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsb, boff(w == 1 ? 2 : 3, h), 0, 0));
+                        const u32x4_t kv = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                            rsb, boff((h == 1 ? 4 : 6) + (w == 1 ? 0 : 1), 0), 0, 0));
+                        chunk_to_f32<T>(cv, g);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) f[e] += g[e];
+                        chunk_to_f32<T>(kv, g);
 #pragma unroll
                         for (int e = 0; e < E; ++e) f[e] += g[e];
                     }
                     return f32_to_chunk<T>(f);
                 };
-                store_tile_via_lds<T, MT, NT>(acc, scratch, lane, b4, d.act, d.slope, rowp, so,
-                                              min(64, HoWo - pw), add, mid);
+                store_tile_via_lds<T, MT, NT>(acc, scratch, lane, nullptr, d.act, d.slope, rowp, so, min(64, HoWo - pw), add);
             } else {
             auto add = [&](int r, int c, const u32x4_t& v, int) -> u32x4_t {
                 const int p = pw + r;
@@ -148,8 +162,7 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
                 if (rb_ & cr_) acc_from(7, 0);
                 return f32_to_chunk<T>(f);
             };
-            store_tile_via_lds<T, MT, NT>(acc, scratch, lane, b4, d.act, d.slope, rowp, so,
-                                          min(64, HoWo - pw), add);
+            store_tile_via_lds<T, MT, NT>(acc, scratch, lane, nullptr, d.act, d.slope, rowp, so, min(64, HoWo - pw), add);
             }
         }
     } else {
@@ -164,10 +177,7 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
                 if (n >= d.Nstore) continue;
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float bv = (bias != nullptr && n + e < d.Nrows) ? bias[n + e] : 0.f;
-                    v[e] = apply_act(acc[a][b][e] + bv, d.act, d.slope);
-                }
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[a][b][e], d.act, d.slope);
                 if (vec_ok) {
                     if constexpr (sizeof(T) == 4) {
                         *reinterpret_cast<f32x4_t*>(yp + n) = f32x4_t{v[0], v[1], v[2], v[3]};

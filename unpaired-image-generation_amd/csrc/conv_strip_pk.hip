@@ -20,7 +20,10 @@
 #include "conv_strip_desc.h"
 #include <algorithm>
 
-template <typename T, int CAP, int DM>
+// SWZ: strip swizzle (1 = rotation, 0 = the XOR of conv_igemm.hip); LGK: wait for this wave's own fragment reads before the
+// K-step barrier (strictly orders them before the DMA that overwrites the weight stage; 0 = rely on the DMA's latency as the
+// one-tile-per-block kernel does); STAMP: diagnostic build writing s_memtime stamps per wave to d.dbg
+template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false>
 __global__ __launch_bounds__(512, 2)
 void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, const float* __restrict__ bias1, T* __restrict__ y,
                           const StripDesc d) {
@@ -78,12 +81,13 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
     zero_rows();
 
     // ---- strip DMA: piece j = strip rows 8j..8j+7; lane L -> row 8j + L/8, physical slot L%8 holding chunk (L%8 - (row & 6)) & 7
-    const unsigned svl = (unsigned)((l8 * Cin + ((ls - (l8 & 6)) & 7) * E) * (int)sizeof(T));
+    const unsigned svl = (unsigned)((l8 * Cin + (SWZ ? ((ls - (l8 & 6)) & 7) : (ls ^ (l8 >> 1))) * E) * (int)sizeof(T));
     auto strip_base = [&](const Tile& t, int cc) -> unsigned {                 // scalar byte offset of (image, first strip row, chunk)
         return (unsigned)__builtin_amdgcn_readfirstlane((((t.img * d.H + t.lo) * d.W) * Cin + cc * BK) * (int)sizeof(T));
     };
+    const unsigned svl_odd = SWZ ? svl : (unsigned)((l8 * Cin + (ls ^ ((l8 >> 1) | 4)) * E) * (int)sizeof(T));   // XOR form: odd pieces flip bit 2
     auto issue_strip_piece = [&](int j, unsigned sbase, int NS, int region) {  // all arguments wave-uniform
-        const unsigned off = (8 * j + l8 < NS) ? svl + (unsigned)(8 * j * Cin * (int)sizeof(T)) : 0xFFFFFFFFu;
+        const unsigned off = (8 * j + l8 < NS) ? ((j & 1) ? svl_odd : svl) + (unsigned)(8 * j * Cin * (int)sizeof(T)) : 0xFFFFFFFFu;
         lds_ptr_t dst = (lds_ptr_t)smem + region * REG + j * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)dst, 16, (int)off, (int)sbase, 0, 0);
     };
@@ -108,6 +112,22 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
         issue_w1(0, t.g2, so, region); issue_w1(1, t.g2, so, region);
     };
 
+    unsigned long long tstamp[8];
+    int nst = 0;
+    auto stamp = [&]() {
+        if constexpr (STAMP) {
+            if (nst < 8) {
+                unsigned long long tt;
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) if (i == nst) tstamp[i] = tt;
+            }
+            ++nst;
+        }
+    };
+    stamp();                                                   // 0: entry
     Tile cur = get_tile(0);
     if (!cur.valid) return;                                    // block-uniform (never taken: the grid is <= the tile count)
     __syncthreads();                                           // zero rows written (no DMA in flight yet)
@@ -141,7 +161,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
             for (int t = 0; t < NTAPS; ++t) {
                 const int s0 = hrow[t / 3] + wcol[t % 3];
                 const int s = (pv & (s0 >= 0)) ? s0 : CAP;
-                rt[t][b] = (unsigned short)(s * 128 + (((q + (s & 6)) & 7) << 4));
+                rt[t][b] = (unsigned short)(s * 128 + ((SWZ ? ((q + (s & 6)) & 7) : (q ^ ((s >> 1) & 7))) << 4));
             }
         }
     };
@@ -154,11 +174,9 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
         const float* bias = cur.g2 ? d.bias2 : bias1;
 
         f32x4_t acc[NT][MT];
-#pragma unroll
-        for (int a = 0; a < NT; ++a)
-#pragma unroll
-            for (int b = 0; b < MT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        strip_init_acc<MT, NT, WN>(acc, bias, d.Nrows, cur.n_base, wn, lane);
 
+        stamp();                                               // 1 / 4: K loop starts
         for (int cc = 0; cc < ncc; ++cc) {
             const int pc = par ^ (cc & 1);                     // region of this chunk's strip; weight stage of step t: pc ^ (t & 1)
             const unsigned char* sx = smem + pc * REG;
@@ -172,7 +190,8 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
             for (int t = 0; t < NTAPS; ++t) {                   // fully unrolled: the row table is statically indexed
                 // this wave's DMAs (weight tile of this step, strip pieces) have landed and its fragment reads of the previous
                 // step are complete (the DMAs issued below overwrite that step's weight stage) ...
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if constexpr (LGK) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();                   // ... and everyone else's
                 const bool last_t = t + 1 == NTAPS;
                 const bool w_on = !(last_t && last_cc) || pre_next;
@@ -208,13 +227,20 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                 }
             }
         }
+        stamp();                                               // 2 / 5: K loop done
         const int pl = par ^ ((ncc - 1) & 1);                  // region of the last chunk == weight stage of the last step (9 taps: odd)
 
         // ---- epilogue: scratch = the region the last K-step has just finished with (the prefetch went to the other one)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                           // every wave is done reading region pl (raw: the prefetch DMAs stay in flight)
         unsigned char* scratch = smem + (XPREF ? pl * REG : 0) + wave * SCRW;
-        strip_epilogue<T, MT, NT, WM, WN>(acc, scratch, d, y, bias, cur.img, cur.p0, wm, wn, cur.n_base, lane);
+        // The epilogue's per-lane constants (LDS scratch addresses, row offsets, ...) all derive from the lane id.  Opaque to the
+        // optimiser here, or it hoists them out of the tile loop and carries ~60 registers through the K loop (seen: 73 VGPRs
+        // spilled to scratch, reloaded one `s_waitcnt vmcnt(0)` at a time behind the epilogue's own global stores).
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        strip_epilogue<T, MT, NT, WM, WN>(acc, scratch, d, y, cur.img, cur.p0, wm, wn, cur.n_base, lane_e);
+        stamp();                                               // 3 / 6: epilogue issued
         if (!nxt.valid) break;
         if constexpr (XPREF) {
             // the scratch covered region pl's zero row: its owner restores it (read again from the next tile's chunk 1 on,
@@ -230,13 +256,18 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
         }
         cur = nxt;
     }
+    if constexpr (STAMP) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp();                                               // last: stores drained
+        if (lane == 0 && d.dbg != nullptr) {
+            unsigned long long* o = d.dbg + ((long)blockIdx.x * NW + wave) * 8;
+            for (int i = 0; i < 8; ++i) o[i] = i < nst ? tstamp[i] : 0ull;
+        }
+    }
 }
 
-template __global__ void conv_strip_pk_kernel<bf16_t, 448, 0>(const bf16_t*, const bf16_t*, const float*, bf16_t*, const StripDesc);
-template __global__ void conv_strip_pk_kernel<bf16_t, 448, 1>(const bf16_t*, const bf16_t*, const float*, bf16_t*, const StripDesc);
-template __global__ void conv_strip_pk_kernel<float, 448, 1>(const float*, const float*, const float*, float*, const StripDesc);
-
-static int g_pk_dm = 1;        // tuning hook: DMA issue placement of the bf16 kernel (0 = top of the step, 1 = spread between MFMA groups)
+static int g_pk_dm = 0;        // tuning hook: variant of the bf16 kernel: bit 0 = DMA issue spread between MFMA groups, bit 1 = XOR swizzle,
+                               // bit 2 = no lgkmcnt wait before the K-step barrier
 static int g_pk_grid = 0;      // tuning hook: persistent grid size (0 = one block per CU)
 extern "C" void uig_debug_set_strip_pk(int dm, int grid) { g_pk_dm = dm; g_pk_grid = grid; }
 
@@ -249,10 +280,10 @@ static int device_cus() {
     return n;
 }
 
-template <typename T, int CAP, int DM>
+template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false>
 static int launch_pk(const void* x, const void* wp, const float* bias, void* y, const StripDesc& d, int ntiles, hipStream_t s) {
     const size_t smem = 2 * ((size_t)(CAP + 8) * 128 + 128 * 128);
-    auto kern = conv_strip_pk_kernel<T, CAP, DM>;
+    auto kern = conv_strip_pk_kernel<T, CAP, DM, SWZ, LGK, STAMP>;
     static SmemAttrOnce attr_once;
     {
         hipError_t e = attr_once.ensure(reinterpret_cast<const void*>(kern), smem);
@@ -277,7 +308,15 @@ int uig_launch_strip_pk(const void* x, const void* wp, const float* bias, void* 
     d.wo_magic = ((1 << 20) + d.Wo - 1) / d.Wo;             // (pr * magic) >> 20 == pr / Wo for pr < Wo + 256 <= 768 (pr * (magic * Wo - 2^20) < 2^20)
     const int tpi = (d.Ho * d.Wo + 255) / 256;
     const int ntiles = d.B * tpi * (d.Nrows / 128);
-    if (dtype == UIG_BF16)
-        return g_pk_dm == 0 ? launch_pk<bf16_t, 448, 0>(x, wp, bias, y, d, ntiles, s) : launch_pk<bf16_t, 448, 1>(x, wp, bias, y, d, ntiles, s);
-    return launch_pk<float, 448, 1>(x, wp, bias, y, d, ntiles, s);
+    if (dtype == UIG_BF16) {
+        if (d.dbg != nullptr) return launch_pk<bf16_t, 448, 0, 1, true, true>(x, wp, bias, y, d, ntiles, s);
+        switch (g_pk_dm) {
+            case 1: return launch_pk<bf16_t, 448, 1, 1, true>(x, wp, bias, y, d, ntiles, s);
+            case 2: return launch_pk<bf16_t, 448, 0, 0, true>(x, wp, bias, y, d, ntiles, s);
+            case 4: return launch_pk<bf16_t, 448, 0, 1, false>(x, wp, bias, y, d, ntiles, s);
+            case 6: return launch_pk<bf16_t, 448, 0, 0, false>(x, wp, bias, y, d, ntiles, s);
+            default: return launch_pk<bf16_t, 448, 0, 1, true>(x, wp, bias, y, d, ntiles, s);
+        }
+    }
+    return launch_pk<float, 448, 0>(x, wp, bias, y, d, ntiles, s);
 }
