@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _build(seed):
+def _build(seed):      # (one generator, one discriminator) for the FlatGroup view test
     from oracle.torch_oracle import Discriminator, Generator, init_weights
     torch.manual_seed(seed)
     return init_weights(Generator(n_blocks=1)), init_weights(Discriminator())
@@ -33,63 +33,123 @@ def _g_loss(G, D, x):
     return F.l1_loss(fake, x) * 10 + F.mse_loss(p, torch.ones_like(p))
 
 
+CUT_MODULES = (10, 11)          # inputs of the oracle generator's two ResBlocks (n_blocks = 2): the staged backward's cut points
+
+
+def _build_pair(seed):
+    from oracle.torch_oracle import Generator, init_weights
+    torch.manual_seed(seed)
+    return init_weights(Generator(n_blocks=2)), init_weights(Generator(n_blocks=2))
+
+
+def _forward_with_taps(nets, xs):
+    """run each net on its input; returns the outputs and, per cut module, the list of that module's input tensors"""
+    taps = {i: [] for i in CUT_MODULES}
+    hooks = [n[i].register_forward_pre_hook(lambda m, inp, i=i: taps[i].append(inp[0])) for n in nets for i in CUT_MODULES]
+    ys = [n(x) for n, x in zip(nets, xs)]
+    for h in hooks:
+        h.remove()
+    return ys, [taps[i] for i in CUT_MODULES]
+
+
+def _pidx(net, module_idx):
+    return sum(len(list(m.parameters())) for m in list(net)[:module_idx])
+
+
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.set_num_threads(2)
-        from unpaired_image_generation_amd.dp import FlatGroup, GradExchange
-        G, D = _build(3)
-        grp_G, grp_D = FlatGroup((G,), "cpu"), FlatGroup((D,), "cpu")
+        from unpaired_image_generation_amd.dp import FlatGroup, GradExchange, run_exchange_phase, staged_backward
+        GA, GB = _build_pair(3)
+        grp = FlatGroup((GA, GB), "cpu")
+        assert grp.interleaved
         xchg = GradExchange()
-        assert xchg.world == world
-        xchg.broadcast(grp_G.flat, 0); xchg.broadcast(grp_D.flat, 0)
+        assert xchg.world == world and xchg.active
+        xchg.broadcast(grp.flat, 0)
         torch.manual_seed(100)
-        x_all = torch.rand(world, 3, 32, 32) * 2 - 1
-        x = x_all[rank:rank + 1]
-        # generator phase on this rank's shard, then the same ordering as the product step:
-        # start G exchange -> run the discriminator phase while it is in flight -> wait -> start D exchange -> Adam
-        grp_G.zero_grad(); grp_D.set_requires_grad(False)
-        _g_loss(G, D, x).backward()
-        grp_D.set_requires_grad(True)
-        h_g = xchg.start(grp_G.grad)
-        grp_D.zero_grad()
-        p = D(G(x).detach())
-        ((p - 0.0) ** 2).mean().backward()
-        xchg.wait(h_g)
-        h_d = xchg.start(grp_D.grad)
-        gG = grp_G.grad / world
-        xchg.wait(h_d)
-        gD = grp_D.grad / world
+        x_all = torch.rand(2, world, 3, 32, 32) * 2 - 1
+        xs = [x_all[0, rank:rank + 1], x_all[1, rank:rank + 1]]
+        cuts_p = [_pidx(GA, i) for i in CUT_MODULES]
+        buckets = grp.buckets(cuts_p)
+        assert len(buckets) == 3 and buckets[0][1] == grp.flat.numel() and buckets[-1][0] == 0
+        assert all(a[0] == b[1] for a, b in zip(buckets, buckets[1:]))            # adjacent, disjoint, covering
+        per = [list(n.parameters()) for n in (GA, GB)]
+        edges = [0] + cuts_p + [len(per[0])]
+        stage_params = [[p for pl in per for p in pl[a:b]] for a, b in reversed(list(zip(edges, edges[1:])))]
+
+        # reference on this rank: ordinary single-call backward
+        grp.zero_grad()
+        ys, _ = _forward_with_taps((GA, GB), xs)
+        sum(y.abs().mean() * 10 for y in ys).backward()
+        local = grp.grad.clone()
+
+        # the product's ordering: staged backward, bucket k exchanged the moment stage k is done
+        grp.zero_grad()
+        ys, cut_tensors = _forward_with_taps((GA, GB), xs)
+        loss = sum(y.abs().mean() * 10 for y in ys)
+        seen = []
+        real_start = xchg.start
+
+        def spy(flat):          # what each bucket held when its all-reduce was started
+            seen.append((flat.data_ptr(), flat.clone()))
+            return real_start(flat)
+        xchg.start = spy
+        handles = run_exchange_phase(staged_backward([loss], cut_tensors, stage_params), xchg, grp.grad, buckets)
+        xchg.wait_all(handles)
+        assert xchg.n_started == len(buckets) == len(seen)
+        for (a, b), (ptr, snap) in zip(buckets, seen):
+            assert ptr == grp.grad[a:b].data_ptr() and snap.numel() == b - a
+            assert torch.equal(snap, local[a:b]), "a bucket was exchanged before its gradients were final"
+        g = grp.grad / world
         if rank == 0:
-            torch.save({"gG": gG.clone(), "gD": gD.clone(), "x": x_all}, out)
-        # both ranks must end with identical buffers
-        chk = torch.stack([gG.double().sum(), gD.double().sum()])
+            torch.save({"g": g.clone(), "x": x_all}, out)
+        chk = g.double().sum().reshape(1)
         lst = [torch.zeros_like(chk) for _ in range(world)]
         dist.all_gather(lst, chk)
-        assert all(torch.equal(lst[0], t) for t in lst)
+        assert all(torch.equal(lst[0], t) for t in lst)                             # identical buffers on every rank
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_dp_gradient_mean_equals_full_batch(tmp_path):
+def test_dp_bucketed_exchange_equals_full_batch(tmp_path):
+    """world 2 (gloo): the product's staged backward + bucketed exchange (dp.staged_backward / run_exchange_phase over the
+    interleaved FlatGroup) - every bucket is final when its all-reduce starts, the buckets tile the flat buffer, and the mean
+    over ranks equals the single-process gradient on the concatenated batch."""
     world, out = 2, str(tmp_path / "dp.pt")
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     got = torch.load(out, weights_only=True)
     from unpaired_image_generation_amd.dp import FlatGroup
-    G, D = _build(3)
-    grp_G, grp_D = FlatGroup((G,), "cpu"), FlatGroup((D,), "cpu")
+    GA, GB = _build_pair(3)
+    grp = FlatGroup((GA, GB), "cpu")
     x = got["x"]
-    grp_D.set_requires_grad(False)
-    _g_loss(G, D, x).backward()
-    grp_D.set_requires_grad(True)
-    grp_D.zero_grad()
-    p = D(G(x).detach())
-    ((p - 0.0) ** 2).mean().backward()
-    for name, a, b in (("G", got["gG"], grp_G.grad), ("D", got["gD"], grp_D.grad)):
-        rel = float((a - b).norm() / b.norm())
-        assert rel < 1e-5, (name, rel)
+    # the per-rank losses are means over one image each: the full-batch equivalent is the mean of the per-image losses
+    loss = sum(n(x[k, r:r + 1]).abs().mean() * 10 for k, n in enumerate((GA, GB)) for r in range(world)) / world
+    loss.backward()
+    rel = float((got["g"] - grp.grad).norm() / grp.grad.norm())
+    assert rel < 1e-5, rel
+
+
+def test_staged_backward_equals_plain_backward():
+    """one process, no collective: cutting the backward pass into stages changes nothing (bitwise on CPU)"""
+    from unpaired_image_generation_amd.dp import FlatGroup, staged_backward
+    GA, GB = _build_pair(9)
+    grp = FlatGroup((GA, GB), "cpu")
+    torch.manual_seed(1)
+    xs = [torch.rand(1, 3, 32, 32), torch.rand(1, 3, 32, 32)]
+    ys, _ = _forward_with_taps((GA, GB), xs)
+    sum(y.abs().mean() for y in ys).backward()
+    ref = grp.grad.clone()
+    grp.zero_grad()
+    ys, cuts = _forward_with_taps((GA, GB), xs)
+    per = [list(n.parameters()) for n in (GA, GB)]
+    edges = [0] + [_pidx(GA, i) for i in CUT_MODULES] + [len(per[0])]
+    stage_params = [[p for pl in per for p in pl[a:b]] for a, b in reversed(list(zip(edges, edges[1:])))]
+    stages = list(staged_backward([sum(y.abs().mean() for y in ys)], cuts, stage_params))
+    assert stages == [0, 1, 2]
+    assert torch.equal(grp.grad, ref)
 
 
 def test_flat_group_views_and_world1_noop():

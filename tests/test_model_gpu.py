@@ -396,6 +396,30 @@ def test_pool_schedule_resume_vs_oracle_fp32(tmp_path):
     m.close(); mr.close()
 
 
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
+def test_staged_backward_step_equals_single_stage(graph):
+    """The data-parallel form of the step (backward cut into 4 + 2 stages at ResBlock / layer boundaries, one HIP graph per
+    stage in graph mode, gradient buckets = contiguous slices of the interleaved flat buffer) without any collective: bitwise
+    the single-stage step over 3 steps - same kernels, same order, same sums."""
+    import unpaired_image_generation_amd as u
+    torch.manual_seed(21)
+    rA, rB = (torch.rand(2, 3, 64, 64, device="cuda") * 2 - 1 for _ in range(2))
+    torch.manual_seed(5)
+    m0 = u.CycleGAN(n_blocks=6, dtype=torch.bfloat16, use_graph=graph)
+    m1 = u.CycleGAN(n_blocks=6, dtype=torch.bfloat16, use_graph=graph, stage_backward=True)
+    m1.load_state_dicts(*[n.state_dict() for n in m0.nets()])
+    assert len(m1.buckets_G) == 4 and len(m1.buckets_D) == 2 and len(m0.buckets_G) == 1
+    assert m1.buckets_G[0][1] == m1.grp_G.flat.numel() and m1.buckets_G[-1][0] == 0
+    assert all(a[0] == b[1] for a, b in zip(m1.buckets_G, m1.buckets_G[1:]))
+    for step in range(3):
+        l0, l1 = m0.train_step(rA, rB), m1.train_step(rA, rB)
+        assert l0 == l1, (step, l0, l1)
+    assert torch.equal(m0.grp_G.flat, m1.grp_G.flat) and torch.equal(m0.grp_D.flat, m1.grp_D.flat)
+    if graph:
+        assert m1.graph_active and len(m1._graphs.g1) == 4 and len(m1._graphs.g2) == 2
+    m0.close(); m1.close()
+
+
 def test_graph_step_with_rccl_exchange_world1_and_close():
     """Guards two aborts seen in round 1 (graph capture with a live process group; process exit with graphs + RCCL alive).
     One worker process = one rank, as in production (the process group lives as long as the process):

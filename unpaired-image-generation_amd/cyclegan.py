@@ -11,8 +11,10 @@ MI355X-first choices (all result-preserving because InstanceNorm statistics are 
     kernel and the data-parallel exchange a single RCCL all-reduce per group;
   * the whole step is static-shape and sync-free, so it is captured once into HIP graphs and replayed
     (segments: G fwd+bwd | D fwd+bwd | Adam G | Adam D), with the gradient all-reduces enqueued between segments on a
-    communication stream: the generator all-reduce overlaps the discriminators' forward+backward, the discriminator
-    all-reduce overlaps the generator Adam.
+    communication stream.  Under data parallelism the backward pass of each phase is cut into stages (4 for the generators,
+    2 for the discriminators) whose slices of the flat gradient buffer are all-reduced while the next stage runs: only the
+    last, smallest bucket (the first layers: 3 MB of 91 MB for the generators) is exposed; the generator update (wait for its
+    buckets, Adam, weight repack) runs on its own stream under the discriminator phase.
 """
 from __future__ import annotations
 
@@ -22,7 +24,7 @@ import os
 import torch
 
 from . import ops
-from .dp import FlatGroup, GradExchange
+from .dp import FlatGroup, GradExchange, run_exchange_phase, staged_backward
 from .networks import Discriminator, Generator, pair_forward_phys
 from .schedule import ImagePool, linear_decay_scale
 
@@ -32,7 +34,7 @@ LOSS_NAMES = ("idt_A", "idt_B", "G_A", "G_B", "cyc_A", "cyc_B", "D_A", "D_B")
 class CycleGAN:
     def __init__(self, n_blocks=9, dtype=torch.bfloat16, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-8,
                  lambda_cyc=10.0, lambda_idt=0.5, device="cuda", process_group=None, use_graph=False, batch_fused=True, paired=True,
-                 force_exchange=False, pool_size=0, pool_seed=0):
+                 force_exchange=False, pool_size=0, pool_seed=0, stage_backward=None):
         self.device, self.dtype = torch.device(device), dtype
         kw = dict(dtype=dtype, device=device)
         self.G_A, self.G_B = Generator(n_blocks=n_blocks, **kw), Generator(n_blocks=n_blocks, **kw)
@@ -49,6 +51,12 @@ class CycleGAN:
         self.defer_join = os.environ.get("UIG_DEFER_JOIN", "1") != "0"
         # generator update (exchange wait, Adam, repack) on its own stream under the discriminator phase (0: after it, on the main stream)
         self.overlap_update = os.environ.get("UIG_OVERLAP_UPDATE", "1") != "0"
+        # data-parallel gradient buckets: the backward pass of each phase is cut into stages and each stage's slice of the flat
+        # gradient buffer is all-reduced under the next stage (dp.staged_backward / run_exchange_phase).  One stage (= the
+        # single-GPU step, bit for bit) when no collective is issued.
+        self.stage_backward = stage_backward            # None: exactly when collectives run; True / False: forced (tests)
+        self.n_stages_G = int(os.environ.get("UIG_DP_STAGES_G", "4"))
+        self.n_stages_D = int(os.environ.get("UIG_DP_STAGES_D", "2"))
         self._graphs = None
         self._finalize_params()
 
@@ -59,7 +67,18 @@ class CycleGAN:
     def _finalize_params(self):
         self.grp_G = FlatGroup((self.G_A, self.G_B), self.device)
         self.grp_D = FlatGroup((self.D_A, self.D_B), self.device)
+        staged = (self.xchg.active if self.stage_backward is None else bool(self.stage_backward)) and self.batch_fused and self.paired
+        self.cuts_G = self.G_A.stage_cut_modules(self.n_stages_G) if staged else []
+        self.cuts_D = self.D_A.stage_cut_modules(self.n_stages_D) if staged else []
+        self.buckets_G = self.grp_G.buckets([self.G_A.param_index_at(i) for i in self.cuts_G])
+        self.buckets_D = self.grp_D.buckets([self.D_A.param_index_at(i) for i in self.cuts_D])
         self.repack()
+
+    def _stage_params(self, nets, cuts):
+        """per backward stage: the parameters (of all `nets`) behind that stage's cut"""
+        edges = [0] + [nets[0].param_index_at(i) for i in cuts] + [len(list(nets[0].parameters()))]
+        per = [list(n.parameters()) for n in nets]
+        return [[p for pl in per for p in pl[a:b]] for a, b in reversed(list(zip(edges, edges[1:])))]
 
     def load_state_dicts(self, sd_GA, sd_GB, sd_DA, sd_DB):
         """Load torch-layout fp32 weights (e.g. from the stock-torch modules) into the flat buffers."""
@@ -105,7 +124,17 @@ class CycleGAN:
     # ------------------------------------------------------------------ step pieces (all async, static shapes)
     def _g_phase(self, xa, xb):
         """generator forward (6 passes) + D forward (frozen) + 6 losses + backward -> grads in grp_G.grad"""
+        res = {}
+        for _ in self._g_stages(xa, xb, res):
+            pass
+        return res["fake_B"], res["fake_A"], res["losses"]
+
+    def _g_stages(self, xa, xb, res):
+        """The generator phase as a Python generator over its backward stages (len(self.cuts_G) + 1 of them; one when no
+        collective runs): yields the stage index after each stage - the gradients of bucket k = self.buckets_G[k] are then
+        complete.  The forward passes and losses run before the first yield.  res receives fake_B, fake_A, losses."""
         B = xa.shape[0]
+        taps = {i: None for i in self.cuts_G} if self.cuts_G else None
         self.grp_D.set_requires_grad(False)
         self.grp_G.zero_grad()
         if self.batch_fused and self.paired:
@@ -114,7 +143,7 @@ class CycleGAN:
             # of the output (no concatenation), and torch.split keeps the backward at ONE concatenation of the three gradient
             # pieces (slicing o four times cost four zero-filled full-size gradients and three adds per step).
             x2 = torch.cat([xb, xa])
-            o = pair_forward_phys(self.G_A, self.G_B, torch.cat([x2, x2]))
+            o = pair_forward_phys(self.G_A, self.G_B, torch.cat([x2, x2]), taps)
             idt_A, ff, idt_B = torch.split(o, [B, 2 * B, B])
             fake_B, fake_A = ff[:B], ff[B:]
             r = pair_forward_phys(self.G_B, self.G_A, ff)          # G_B(fake_B) = rec_A ; G_A(fake_A) = rec_B
@@ -140,23 +169,44 @@ class CycleGAN:
         l_cyc_A = ops.l1_loss(rec_A, xa, self.lam, n_real, True)
         l_cyc_B = ops.l1_loss(rec_B, xb, self.lam, n_real, True)
         losses = [l_idt_A, l_idt_B, l_G_A, l_G_B, l_cyc_A, l_cyc_B]
-        with ops.deferred_param_grads(self.device) if self.defer_join else contextlib.nullcontext():
-            ops.backward_unit(losses)
+        res.update(fake_B=fake_B.detach(), fake_A=fake_A.detach(), losses=losses)
+        self.last_fake_B = res["fake_B"]
+        ctx = (lambda k: ops.deferred_param_grads(self.device)) if self.defer_join else None
+        if taps:
+            # pass 1 (the 4B-image pass) is the LAST part of the backward pass and a chain through its ResBlocks: cut there
+            cuts = [taps[i] for i in self.cuts_G]
+            yield from staged_backward(losses, cuts, self._stage_params((self.G_A, self.G_B), self.cuts_G), ctx)
+        else:
+            with ctx(0) if ctx else contextlib.nullcontext():
+                ops.backward_unit(losses)
+            yield 0
         self.grp_D.set_requires_grad(True)
-        self.last_fake_B = fake_B.detach()
-        return fake_B.detach(), fake_A.detach(), losses
 
     def _d_phase(self, xa, xb, fake_B, fake_A):
+        res = {}
+        for _ in self._d_stages(xa, xb, fake_B, fake_A, res):
+            pass
+        return res["losses"]
+
+    def _d_stages(self, xa, xb, fake_B, fake_A, res):
+        """The discriminator phase as a generator over its backward stages (see _g_stages); res["losses"] = [(real, fake) x 2]."""
         self.grp_D.zero_grad()
         B = xa.shape[0]
         out = []
         if self.batch_fused and self.paired:      # D_A on [real_B; fake_B] and D_B on [real_A; fake_A] as one paired pass
-            p = torch.split(pair_forward_phys(self.D_A, self.D_B, torch.cat([xb, fake_B, xa, fake_A])), B)
+            taps = {i: None for i in self.cuts_D} if self.cuts_D else None
+            p = torch.split(pair_forward_phys(self.D_A, self.D_B, torch.cat([xb, fake_B, xa, fake_A]), taps), B)
             ls = [ops.mse_const(p[0], 1.0, 0.5, True), ops.mse_const(p[1], 0.0, 0.5, True),
                   ops.mse_const(p[2], 1.0, 0.5, True), ops.mse_const(p[3], 0.0, 0.5, True)]
-            with ops.deferred_param_grads(self.device) if self.defer_join else contextlib.nullcontext():
-                ops.backward_unit(ls)
-            return [(ls[0], ls[1]), (ls[2], ls[3])]
+            res["losses"] = [(ls[0], ls[1]), (ls[2], ls[3])]
+            ctx = (lambda k: ops.deferred_param_grads(self.device)) if self.defer_join else None
+            if taps:
+                yield from staged_backward(ls, [taps[i] for i in self.cuts_D], self._stage_params((self.D_A, self.D_B), self.cuts_D), ctx)
+            else:
+                with ctx(0) if ctx else contextlib.nullcontext():
+                    ops.backward_unit(ls)
+                yield 0
+            return
         for D, real, fake in ((self.D_A, xb, fake_B), (self.D_B, xa, fake_A)):
             if self.batch_fused:
                 p = D.forward_phys(torch.cat([real, fake]))
@@ -165,7 +215,8 @@ class CycleGAN:
                 l_real, l_fake = ops.mse_const(D.forward_phys(real), 1.0, 0.5, True), ops.mse_const(D.forward_phys(fake), 0.0, 0.5, True)
             ops.backward_unit([l_real, l_fake])
             out.append((l_real, l_fake))
-        return out
+        res["losses"] = out
+        yield 0
 
     def _adam(self, grp):
         grp.step += 1
@@ -224,22 +275,24 @@ class CycleGAN:
         depend on the discriminator phase and the discriminator phase does not read the generators' weights, so the update
         runs on its own stream UNDER the discriminators' forward+backward (it was ~0.45 ms of the critical path)."""
         main, upd = torch.cuda.current_stream(self.device), self._update_stream()
-        fake_B, fake_A, lg = self._g_phase(xa, xb)
-        h_g = self.xchg.start(self.grp_G.grad)           # overlaps the whole discriminator phase
+        rg, rd = {}, {}
+        # bucket k's all-reduce starts the moment backward stage k has produced it and runs under the stages that follow
+        h_g = run_exchange_phase(self._g_stages(xa, xb, rg), self.xchg, self.grp_G.grad, self.buckets_G)
+        fake_B, fake_A, lg = rg["fake_B"], rg["fake_A"], rg["losses"]
         if self.overlap_update:
             upd.wait_stream(main)
             with torch.cuda.stream(upd):
-                self.xchg.wait(h_g, self.device)
+                self.xchg.wait_all(h_g, self.device)
                 self._adam(self.grp_G)
                 self._packer_of("G").run()
         fake_B, fake_A = self._pool_fakes(fake_B, fake_A)
-        ld = self._d_phase(xa, xb, fake_B, fake_A)
+        h_d = run_exchange_phase(self._d_stages(xa, xb, fake_B, fake_A, rd), self.xchg, self.grp_D.grad, self.buckets_D)
+        ld = rd["losses"]
         if not self.overlap_update:
-            self.xchg.wait(h_g, self.device)
+            self.xchg.wait_all(h_g, self.device)
             self._adam(self.grp_G)
             self._packer_of("G").run()
-        h_d = self.xchg.start(self.grp_D.grad)
-        self.xchg.wait(h_d, self.device)
+        self.xchg.wait_all(h_d, self.device)
         self._adam(self.grp_D)
         self._packer_of("D").run()
         main.wait_stream(upd)
@@ -265,7 +318,7 @@ class CycleGAN:
         if st is not None:
             for name in ("g4", "g3", "g2", "g1"):
                 if hasattr(st, name):
-                    delattr(st, name)
+                    delattr(st, name)                       # g1 / g2 are lists of stage graphs
             st.__dict__.clear()
         del st
         self.__dict__.pop("_packers", None)

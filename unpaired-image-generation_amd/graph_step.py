@@ -1,13 +1,15 @@
-"""HIP-graph execution of the train step: the static-shape, sync-free step is captured once into four graphs
-(G fwd+bwd | D fwd+bwd | Adam G + repack G | Adam D + repack D) and replayed; data-parallel all-reduces are enqueued
-between the replays on the communication stream and the generator update graph is replayed on its own stream, so the
-generator exchange, Adam and weight repack all run under the discriminators' forward+backward.
+"""HIP-graph execution of the train step: the static-shape, sync-free step is captured once into graphs
+(G fwd+bwd | D fwd+bwd | Adam G + repack G | Adam D + repack D) and replayed.  Under data parallelism each phase's backward
+pass is cut into stages (cyclegan._g_stages / _d_stages) and every stage is its own graph: bucket k's all-reduce is enqueued
+on the communication stream between the replays of stage k and stage k+1 and runs under the latter; the generator update
+graph (wait for the buckets, Adam, weight repack) is replayed on its own stream under the discriminators' forward+backward.
 Replaces a tracing compiler: one capture of the hand-written kernel sequence, no per-op host overhead afterwards."""
 from __future__ import annotations
 
 import torch
 
 from . import ops
+from .dp import run_exchange_phase
 
 
 class _Captured:
@@ -42,23 +44,40 @@ def _capture(model, real_A, real_B):
     model.pool_B.load_state_dict(pools[0]); model.pool_A.load_state_dict(pools[1])
     model.repack()                                   # the warm-up step left the kernel operands at its own updated weights
 
-    st.g1, st.g2, st.g3, st.g4 = (torch.cuda.CUDAGraph() for _ in range(4))
+    st.g3, st.g4 = (torch.cuda.CUDAGraph() for _ in range(2))
+    st.g1 = [torch.cuda.CUDAGraph() for _ in model.buckets_G]      # one graph per backward stage (one in all when no collective runs)
+    st.g2 = [torch.cuda.CUDAGraph() for _ in model.buckets_D]
     # capture_error_mode thread_local: with a process group alive, RCCL's watchdog thread polls its events (hipEventQuery)
     # while this thread captures; under the default global mode that poll is an illegal call DURING CAPTURE and aborts the
     # process (seen in 5 of 8 launches under torchrun).
     cem = dict(capture_error_mode="thread_local")
-    with torch.cuda.graph(st.g1, **cem):
-        st.xa, st.xb = model.to_phys(st.real_A), model.to_phys(st.real_B)
-        st.fake_B, st.fake_A, lg = model._g_phase(st.xa, st.xb)
-        st.lg = torch.cat([l.detach() for l in lg])
-    pool = st.g1.pool()
+    rg, rd = {}, {}
+    pool = None
+    gen = None
+    for k, g in enumerate(st.g1):
+        with torch.cuda.graph(g, **(dict(pool=pool) if pool is not None else {}), **cem):
+            if k == 0:
+                st.xa, st.xb = model.to_phys(st.real_A), model.to_phys(st.real_B)
+                gen = model._g_stages(st.xa, st.xb, rg)
+            assert next(gen) == k
+            if k == len(st.g1) - 1:
+                assert next(gen, None) is None                 # run the generator's tail (un-freeze D) inside the capture
+                st.fake_B, st.fake_A = rg["fake_B"], rg["fake_A"]
+                st.lg = torch.cat([l.detach() for l in rg["losses"]])
+        pool = st.g1[0].pool()
     # the discriminators read their fakes from static buffers: the image pools (if enabled) fill them between the replays
     st.pooled = model.pool_B.size > 0
     st.dfake_B = torch.empty_like(st.fake_B) if st.pooled else st.fake_B
     st.dfake_A = torch.empty_like(st.fake_A) if st.pooled else st.fake_A
-    with torch.cuda.graph(st.g2, pool=pool, **cem):
-        ld = model._d_phase(st.xa, st.xb, st.dfake_B, st.dfake_A)
-        st.losses = torch.cat([st.lg, ld[0][0].detach() + ld[0][1].detach(), ld[1][0].detach() + ld[1][1].detach()])
+    for k, g in enumerate(st.g2):
+        with torch.cuda.graph(g, pool=pool, **cem):
+            if k == 0:
+                gen = model._d_stages(st.xa, st.xb, st.dfake_B, st.dfake_A, rd)
+            assert next(gen) == k
+            if k == len(st.g2) - 1:
+                assert next(gen, None) is None
+                ld = rd["losses"]
+                st.losses = torch.cat([st.lg, ld[0][0].detach() + ld[0][1].detach(), ld[1][0].detach() + ld[1][1].detach()])
     with torch.cuda.graph(st.g3, pool=pool, **cem):
         g = model.grp_G
         ops.adam_flat_graph(g.flat, g.grad, g.m, g.v, model.lr, model.b1, model.b2, model.eps, g.state16, 1.0 / model.world)
@@ -89,21 +108,25 @@ def graph_train_step(model, real_A, real_B):
     st.real_A.copy_(real_A, non_blocking=True)
     st.real_B.copy_(real_B, non_blocking=True)
     main, upd = torch.cuda.current_stream(model.device), model._update_stream()
-    st.g1.replay()
-    h_g = model.xchg.start(model.grp_G.grad)      # exchange, Adam and repack of the generators run under the discriminator graph
-    if model.overlap_update:
+    def replay_stages(graphs):
+        for k, g in enumerate(graphs):
+            g.replay()
+            yield k
+
+    # bucket k's all-reduce is enqueued right behind stage k's graph and runs under stage k+1's
+    h_g = run_exchange_phase(replay_stages(st.g1), model.xchg, model.grp_G.grad, model.buckets_G)
+    if model.overlap_update:      # exchange wait, Adam and repack of the generators run under the discriminator graphs
         upd.wait_stream(main)
         with torch.cuda.stream(upd):
-            model.xchg.wait(h_g, model.device)
+            model.xchg.wait_all(h_g, model.device)
             st.g3.replay()
     if st.pooled:
         model._pool_fakes(st.fake_B, st.fake_A, st.dfake_B, st.dfake_A)
-    st.g2.replay()
+    h_d = run_exchange_phase(replay_stages(st.g2), model.xchg, model.grp_D.grad, model.buckets_D)
     if not model.overlap_update:
-        model.xchg.wait(h_g, model.device)
+        model.xchg.wait_all(h_g, model.device)
         st.g3.replay()
-    h_d = model.xchg.start(model.grp_D.grad)
-    model.xchg.wait(h_d, model.device)
+    model.xchg.wait_all(h_d, model.device)
     st.g4.replay()
     main.wait_stream(upd)
     model.grp_G.step += 1

@@ -136,6 +136,32 @@ class _PhysNet(nn.Sequential):
         for m in self.conv_layers():
             m.repack()
 
+    def param_index_at(self, module_idx: int) -> int:
+        """number of parameters (in parameters() order) held by the modules in front of self[module_idx]"""
+        return sum(len(list(m.parameters())) for m in list(self)[:module_idx])
+
+    def stage_cut_modules(self, n_stages: int):
+        """Module indices at whose INPUT the backward pass may be cut into `n_stages` stages (data-parallel gradient buckets),
+        ascending.  Candidates: inputs of ResBlocks and of convolutions fed by an InstanceNorm / activation slot - the incoming
+        gradient there is consumed by an InstanceNorm (or conv-epilogue activation) backward, which reads no side-channel
+        attribute from it (the conv <- norm bias-gradient hand-off `_uig_colsum` never crosses such a boundary).
+        Chosen greedily from the END of the network (backward order) so that every stage but the last carries about the same
+        number of parameter bytes; the last stage (the first layers) takes what is left."""
+        mods = list(self)
+        cand = [i for i, m in enumerate(mods) if i > 0 and (isinstance(m, ResBlock) or (isinstance(m, ConvLayer) and isinstance(mods[i - 1], _Slot)))
+                and self.param_index_at(i) > 0]
+        if n_stages <= 1 or not cand:
+            return []
+        numel = [sum(p.numel() for p in m.parameters()) for m in mods]
+        total = sum(numel)
+        target = total / float(n_stages)
+        cuts, acc = [], 0
+        for i in range(len(mods) - 1, 0, -1):
+            acc += numel[i]
+            if i in cand and acc >= target and len(cuts) < n_stages - 1:
+                cuts.append(i); acc = 0
+        return sorted(cuts)
+
 
 class Generator(_PhysNet):
     """ResNet generator (Appendix A): c7s1-64, d128, d256, n_blocks x R256, u128, u64, c7s1-3 + tanh."""
@@ -174,10 +200,11 @@ class Discriminator(_PhysNet):
         self._mark_in_producers()
 
 
-def pair_forward_phys(net1: _PhysNet, net2: _PhysNet, x: torch.Tensor) -> torch.Tensor:
+def pair_forward_phys(net1: _PhysNet, net2: _PhysNet, x: torch.Tensor, taps: dict | None = None) -> torch.Tensor:
     """Run two networks of identical architecture in lockstep on one stacked batch: the first half of x goes through net1,
     the second half through net2, every convolution as ONE paired launch (ops.PairConvFn); InstanceNorm / activations are
-    per-sample and simply see the whole batch.  Numerically identical to net1(x[:h]) and net2(x[h:])."""
+    per-sample and simply see the whole batch.  Numerically identical to net1(x[:h]) and net2(x[h:]).
+    taps: {module index: None} is filled with the INPUT tensor of those modules (cut points of the staged backward)."""
     if x.shape[0] % 2:
         raise ValueError("pair_forward_phys: the stacked batch must be even")
     g = x.shape[0] // 2
@@ -188,7 +215,9 @@ def pair_forward_phys(net1: _PhysNet, net2: _PhysNet, x: torch.Tensor) -> torch.
         l1.ensure_packed(); l2.ensure_packed()
         return ops.PairConvFn.apply(t, l1.weight, l1.bias, l2.weight, l2.bias, l1, l2, g, link)
 
-    for m1, m2 in zip(net1, net2):
+    for idx, (m1, m2) in enumerate(zip(net1, net2)):
+        if taps is not None and idx in taps:
+            taps[idx] = x
         if isinstance(m1, ConvLayer):
             x = conv(m1, m2, x)
         elif isinstance(m1, ResBlock):
