@@ -23,6 +23,7 @@ F_G256 = 99.10e9      # generator forward FLOPs / image @256^2 (SURVEY.md §2.3,
 F_D256 = 6.29e9       # discriminator forward FLOPs / image
 PEAK_BF16 = 2.5e15    # dense bf16 MFMA peak (MI355X_MICROARCH.md: Chip-level parameters)
 PEAK_F32 = 157.3e12
+PEAK_FP8 = 5.0e15     # dense MX-scaled fp8 MFMA peak
 
 
 def step_flops(size, n_blocks=9):
@@ -37,7 +38,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4, help="pairs per GPU")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
+                    help="fp8: BASELINE configs[4] (use --batch 8): ResBlock convs fwd + dgrad on MX block-scaled fp8 MFMA, bf16 elsewhere")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=100)
@@ -61,9 +63,9 @@ def main():
 
     import unpaired_image_generation_amd as u
     assert u.lib.lib().uig_device_ok() == 1, "bench.py needs an MI355X (gfx950)"
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
     torch.manual_seed(0)                                   # identical replicas on every rank
-    model = u.CycleGAN(n_blocks=9, dtype=dtype, device=dev, use_graph=not args.no_graph, force_exchange=args.force_comm)
+    model = u.CycleGAN(n_blocks=9, dtype=dtype, device=dev, use_graph=not args.no_graph, force_exchange=args.force_comm, fp8=args.dtype == "fp8")
     model.broadcast_params(0)
     torch.manual_seed(1000 + rank)                         # different data shard per rank
     B, S = args.batch, args.size
@@ -98,15 +100,16 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"CycleGAN train step: 9-block G_A/G_B + 70x70 PatchGAN D_A/D_B, {S}x{S}, "
-                               f"batch {B}/GPU, {args.dtype} MFMA conv path, fp32 master weights + Adam",
+                               f"batch {B}/GPU, " + ("MX block-scaled fp8 (e4m3, one E8M0 scale per 32 channels) ResBlock convs fwd+dgrad, bf16 elsewhere"
+                                                     if args.dtype == "fp8" else f"{args.dtype} MFMA conv path") + ", fp32 master weights + Adam",
                    "global_batch": world * B, "image": f"3x{S}x{S}", "parallelism": f"dp{world}",
                    "hip_graph": model.graph_active},
         "step_tflops": round(sf * B / (ms * 1e-3) / 1e12, 2),
-        "step_mfma_frac": round(sf * B / (ms * 1e-3) / (PEAK_BF16 if args.dtype == "bf16" else PEAK_F32), 4),
+        "step_mfma_frac": round(sf * B / (ms * 1e-3) / (PEAK_F32 if args.dtype == "f32" else PEAK_BF16), 4),
         "losses": {k: round(v, 4) for k, v in losses.items()},
     }
     if rank == 0:
-        out["roofline"] = dominant_kernel_roofline(u, torch, dev, dtype, 4 * B, S // 4, args.kernel_iters)
+        out["roofline"] = dominant_kernel_roofline(u, torch, dev, dtype, 4 * B, S // 4, args.kernel_iters, fp8=args.dtype == "fp8")
         out["g_fwd"] = generator_forward_mfma(u, torch, model, dev, dtype, B, S)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch, S, B)
@@ -156,23 +159,32 @@ def generator_forward_mfma(u, torch, model, dev, dtype, B, S):
             "flops": flops, "target_mfma_frac": 0.40}
 
 
-def dominant_kernel_roofline(u, torch, dev, dtype, nimg, hw, iters):
+def dominant_kernel_roofline(u, torch, dev, dtype, nimg, hw, iters, fp8=False):
     """The ResBlock 3x3 reflect-pad conv (256->256 on hw x hw) exactly as the step launches it most often: ONE paired launch
     over the 4B-image stack [G_A: real_A, real_B | G_B: real_B, real_A] (two weight sets).  88 % of generator FLOPs.
     HIP events (torch.cuda.Event on the launch stream) around `iters` back-to-back launches on random data."""
     from unpaired_image_generation_amd import ops, networks
     l1 = networks.ConvLayer("conv", 256, 256, 3, 1, 1, "reflect", dtype=dtype, device=dev)
     l2 = networks.ConvLayer("conv", 256, 256, 3, 1, 1, "reflect", dtype=dtype, device=dev)
+    if fp8:
+        l1.enable_fp8(); l2.enable_fp8()
     l1.repack(); l2.repack()
     x = (torch.rand(nimg, hw, hw, 256, device=dev) * 2 - 1).to(dtype)
     pair = (l2.wp_fwd, l2.bias, nimg // 2)
+    if fp8:      # the fp8 kernel alone, on pre-quantised operands (the quantisation pass is a separate, HBM-bound kernel)
+        xq, xs = ops.mx_quantize(x)
+        y = torch.empty_like(x)
+        mx = (l1.wq_fwd, l1.ws_fwd, l2.wq_fwd, l2.ws_fwd)
+        launch = lambda: ops._conv3x3_mx(xq, xs, mx, l1.bias, l2.bias, nimg // 2, y, 256, u.lib.PAD_REFLECT, u.lib.GATHER_DIRECT, u.lib.ACT_NONE, 0.0)
+    else:
+        launch = lambda: ops.conv_forward(l1.spec, x, l1.wp_fwd, l1.bias, pair=pair)
     # back-to-back launches; the first third is warm-up (the clock the chip settles at under this load is what counts:
     # five warm-up launches after the host-side pause that follows the training loop read 20 % slow), the rest is timed
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for i in range(3 * iters):
         if i == iters:
             e0.record()
-        ops.conv_forward(l1.spec, x, l1.wp_fwd, l1.bias, pair=pair)
+        launch()
     e1.record()
     e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (2 * iters)
@@ -185,17 +197,18 @@ def dominant_kernel_roofline(u, torch, dev, dtype, nimg, hw, iters):
     traffic_from_profile = None
     try:
         pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_dominant_pmc.json"))
-        if pmc and dtype == torch.bfloat16:
+        if pmc and dtype == torch.bfloat16 and not fp8:
             j = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))
             if j.get("images") == nimg and j.get("hw") == hw:
                 traffic_from_profile = {"hbm_bytes_per_launch": j.get("hbm_bytes_per_launch"), "file": "profiles/" + pmc[-1],
                                         "kernel": j.get("kernel")}
     except OSError:
         pass
-    alg = (nimg * hw * hw * 256 * 2) * 2 + 2 * 256 * 2304 * 2
-    kid = u.lib.lib().uig_debug_last_conv_kernel()
-    kname = {u.lib.K_STRIP_PK: "conv_strip_pk_kernel<%s,448> (256x128 tiles, persistent blocks)", u.lib.K_STRIP256: "conv_strip_kernel<%s,256,128>"}.get(kid, "kernel id %d <%%s>" % kid)
-    return {"kernel": (kname + " conv3x3 256->256 reflect, paired G_A|G_B launch (ResBlock fwd)") % ("bf16" if dtype == torch.bfloat16 else "f32"),
+    eb = 1 if fp8 else (2 if dtype == torch.bfloat16 else 4)      # operand bytes per element (the output is bf16 on the fp8 path)
+    alg = nimg * hw * hw * 256 * (eb + (2 if fp8 else eb)) + 2 * 256 * 2304 * eb
+    kid = u.lib.lib().uig_debug_last_conv_kernel() if not fp8 else -1
+    kname = {-1: "conv_strip_fp8_kernel<448> (MX e4m3 v_mfma_scale_f32_16x16x128, 256x128 tiles, persistent blocks) [%s operands]",u.lib.K_STRIP_PK: "conv_strip_pk_kernel<%s,448> (256x128 tiles, persistent blocks)", u.lib.K_STRIP256: "conv_strip_kernel<%s,256,128>"}.get(kid, "kernel id %d <%%s>" % kid)
+    return {"kernel": (kname + " conv3x3 256->256 reflect, paired G_A|G_B launch (ResBlock fwd)") % ("fp8" if fp8 else "bf16" if dtype == torch.bfloat16 else "f32"),
             "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
             "frac": round(ach / peak, 4), "traffic": None, "traffic_from_profile": traffic_from_profile, "algorithmic_bytes": alg,
             "avg_us": round(us, 2), "gemm": f"M={nimg * hw * hw} N=256 K=2304 (2 weight sets)", "flops_per_launch": flops}

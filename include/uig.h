@@ -93,6 +93,24 @@ int uig_conv_gather_ex(const void* x, const void* wp, const float* bias, const v
 int uig_reflect3x3_dgrad_border(const void* dy, const void* wp, const void* wp2, int group_images, void* bord,
                                 int B, int H, int W, int C, int Nrows, int ldc, int dtype, void* stream);
 int uig_conv_strip_applicable(int B, int H, int W, int Cin, int Nrows, int Ho, int Wo, int dh_min, int dh_max, int dtype);
+
+/* ---- MX block-scaled fp8 path (BASELINE.json configs[4]): the 3x3 stride-1 pad-1 convolutions (forward: gather_mode direct,
+ * zero or reflection padding; input gradient: gather_mode transposed, zero padding + border_add) on
+ * v_mfma_scale_f32_16x16x128_f8f6f4.  Operands: OCP e4m3 bytes with one E8M0 scale byte per 32 consecutive channels
+ * (uig_mx_quantize): xq (B,H,W,Cin) + xs (B,H,W,Cin/32); wq [Nrows][9][Cin] + ws [Nrows][9][Cin/32] (quantise the packed
+ * bf16 operand of uig_pack_weight as a [Nrows*9][Cin] matrix).  fp32 accumulate, bf16 output y (B,H,W,ldc); bias, paired
+ * launch (wq2 / ws2 / bias2 / group_images), in_partial, border_add, res_add as in uig_conv_gather_ex.
+ * Needs Cin and Nrows multiples of 128 and 256-pixel strips of at most 448 rows (uig_conv3x3_mx_fp8_applicable). */
+int uig_conv3x3_mx_fp8_applicable(int B, int H, int W, int Cin, int Nrows);
+int uig_conv3x3_mx_fp8(const void* xq, const void* xs, const void* wq, const void* ws, const float* bias,
+                       const void* wq2, const void* ws2, const float* bias2, int group_images,
+                       float* in_partial, const void* border_add, const void* res_add, void* y,
+                       int B, int H, int W, int Cin, int Nrows, int pad_mode, int gather_mode, int ldc,
+                       int act, float slope, void* stream);
+/* MX quantisation along the last axis of a [P][C] matrix (dtype UIG_F32 / UIG_BF16), C a multiple of 32: per block of 32,
+ * scale = 2^(floor(log2(max|x|)) - 8) as an E8M0 byte (127 for an all-zero block), elements = RNE(x / scale) in e4m3,
+ * saturated to +-448.  q: [P][C] bytes, scales: [P][C/32] bytes. */
+int uig_mx_quantize(const void* x, void* q, void* scales, long P, int C, int dtype, void* stream);
 /* which strip kernel that launch runs on: 0 none (generic gather), 128 = 128x128 tiles, 256 = 256x128 tiles one per block,
  * 257 = 256x128 tiles on persistent blocks (tests assert the variant they mean to cover) */
 int uig_conv_strip_tile(int B, int H, int W, int Cin, int Nrows, int Ho, int Wo, int dh_min, int dh_max, int dtype);

@@ -1,0 +1,133 @@
+"""MX block-scaled fp8 path (BASELINE.json configs[4]) against its same-rounding CPU emulation (oracle/mx_fp8.py).
+PARITY UNPINNED BY THE REFERENCE (no reference implementation or fixture exists): the emulation restates the OCP MX format
+with stock torch's float8_e4m3fn cast.  Stated tolerances:
+  * quantiser: e4m3 bytes and E8M0 scale bytes identical, byte for byte;
+  * convolution on identical quantised operands: 1.6e-2 * max|ref| (fp32 accumulation order + the bf16 rounding of the output,
+    the same bound as the bf16 operator tests);
+  * against the UNQUANTISED fp32 convolution: 8 % of max|ref| (e4m3 has 3 mantissa bits: 2^-4 relative per element; the error
+    of a 2304-term dot product of independently rounded terms stays well below that)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    import unpaired_image_generation_amd as u
+    from unpaired_image_generation_amd import ops, networks
+    assert u.lib.lib().uig_device_ok() == 1, "no gfx950 device visible"
+    return u, ops, networks
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_mx_quantize_bytes_equal_emulation(dtype):
+    u, ops, networks = _mods()
+    from oracle import mx_fp8 as M
+    torch.manual_seed(3)
+    x = torch.randn(257, 256) * torch.logspace(-6, 5, 257).unsqueeze(1)          # 11 decades of block magnitudes
+    x[5] = 0.0                                                                   # all-zero blocks -> scale 1.0
+    x[7, :32] = torch.tensor([448.0, 464.0, 465.0, 480.0, 511.0, -448.0, -500.0, 3e-3] * 4)   # around the saturation point
+    x[9, ::3] = 0.0
+    x = x.to(dtype)
+    q, s = ops.mx_quantize(x.cuda())
+    qr, sr = M.mx_quantize(x)
+    assert torch.equal(s.cpu(), sr), "E8M0 scale bytes differ"
+    assert torch.equal(q.cpu(), qr), f"{int((q.cpu() != qr).sum())} e4m3 bytes differ"
+
+
+@pytest.mark.parametrize("B,group,S", [(16, 8, 64), (8, 0, 64), (5, 2, 32)], ids=["paired16", "single8", "paired5-32px"])
+def test_conv3x3_mx_fp8_forward_and_dgrad_vs_emulation(B, group, S):
+    """The ResBlock convolution (256->256 3x3 reflect) on the MX fp8 kernel: forward (+ fused InstanceNorm statistics) and the
+    input gradient (main term on fp8; mirrored-border terms on bf16; + the ResBlock skip gradient) against the emulation."""
+    u, ops, networks = _mods()
+    from oracle import mx_fp8 as M
+    lib, dt = u.lib.lib(), torch.bfloat16
+    torch.manual_seed(2000 + B)
+    g = group if group else B
+    ls = [networks.ConvLayer("conv", 256, 256, 3, 1, 1, "reflect", dtype=dt, device="cuda") for _ in range(2 if group else 1)]
+    ws = [torch.randn(256, 256, 3, 3) * 0.03 for _ in ls]
+    bs = [torch.randn(256) * 0.1 for _ in ls]
+    for l, w, b in zip(ls, ws, bs):
+        with torch.no_grad():
+            l.weight.copy_(w); l.bias.copy_(b)
+        l.emit_in_stats = True
+        l.enable_fp8()
+        l.ensure_packed()
+        assert l.mx_active(B, S, S)
+    x = (torch.rand(B, 256, S, S) * 2 - 1) * torch.logspace(-1, 1, 256).view(1, 256, 1, 1)     # channel scales spanning 2 decades
+    dy = torch.randn(B, 256, S, S) * 0.5
+    res = torch.randn(B, 256, S, S) * 0.5
+    bf = lambda t: t.to(dt).float()
+    parts = [(0, g, 0)] + ([(g, B, 1)] if group else [])
+    # ---- emulation: forward on MX-quantised operands; plain fp32 conv for the looser bound
+    yref = torch.cat([M.conv3x3_mx_forward(bf(x[a:e]), ws[i], bs[i], True) for a, e, i in parts])
+    yfull = torch.cat([F.conv2d(F.pad(bf(x[a:e]), (1, 1, 1, 1), mode="reflect"), bf(ws[i]), bs[i]) for a, e, i in parts])
+    # ---- device
+    xp = ops.to_nhwc(x.cuda(), dt).requires_grad_(True)
+    link = ops.SkipLink()
+    if group:
+        yp = ops.PairConvFn.apply(xp, ls[0].weight, ls[0].bias, ls[1].weight, ls[1].bias, ls[0], ls[1], g, link)
+    else:
+        yp = ops.ConvFn.apply(xp, ls[0].weight, ls[0].bias, ls[0], link)
+    y = ops.from_nhwc(yp, 256).cpu()
+    scale = float(yref.abs().max())
+    e1, e2 = float((y - yref).abs().max()), float((y - yfull).abs().max())
+    print(f"fwd: vs emulation {e1:.3e} ({e1 / scale:.2e} of max), vs unquantised {e2:.3e} ({e2 / scale:.2e} of max)")
+    assert e1 <= 1.6e-2 * scale, "forward vs same-rounding emulation"
+    assert e2 <= 8e-2 * scale, "forward vs unquantised convolution"
+    assert getattr(yp, "_uig_in_partial", None) is not None
+    z = ops.InstNormActFn.apply(yp, None, u.lib.ACT_RELU, 0.0, 1e-5)
+    zref = F.relu(F.instance_norm(ops.from_nhwc(yp.detach(), 256).cpu(), eps=1e-5))
+    assert (ops.from_nhwc(z.detach(), 256).cpu() - zref).abs().max() <= 1.6e-2 * float(zref.abs().max())
+    # ---- input gradient: fp8 main term (zero-pad transposed conv of the quantised dy) + bf16 border terms + residual
+    link.grad = ops.to_nhwc(res.cuda(), dt)
+    yp.backward(ops.to_nhwc(dy.cuda(), dt))
+    dx = ops.from_nhwc(xp.grad, 256).cpu()
+    main = torch.cat([M.conv3x3_mx_dgrad_zero_pad(bf(dy[a:e]), ws[i]) for a, e, i in parts])
+    # the exact reflection gradient minus the exact zero-pad gradient = the border terms (computed by the bf16 border GEMM)
+    xr = bf(x).requires_grad_(True)
+    full = torch.cat([F.conv2d(F.pad(xr[a:e], (1, 1, 1, 1), mode="reflect"), bf(ws[i])) for a, e, i in parts])
+    full.backward(bf(dy))
+    zp = torch.cat([F.conv_transpose2d(bf(dy[a:e]), bf(ws[i]), None, 1, 1) for a, e, i in parts])
+    dxref = main + (xr.grad - zp) + bf(res)
+    dxfull = xr.grad + bf(res)
+    sc = float(dxfull.abs().max())
+    d1, d2 = float((dx - dxref).abs().max()), float((dx - dxfull).abs().max())
+    print(f"dgrad: vs emulation {d1:.3e} ({d1 / sc:.2e} of max), vs unquantised {d2:.3e} ({d2 / sc:.2e} of max)")
+    assert d1 <= 1.6e-2 * sc, "input gradient vs same-rounding emulation"
+    assert d2 <= 8e-2 * sc, "input gradient vs unquantised gradient"
+    # weight / bias gradients stay on the bf16 path
+    wr = [bf(w).requires_grad_(True) for w in ws]
+    br = [b.clone().requires_grad_(True) for b in bs]
+    y2 = torch.cat([F.conv2d(F.pad(bf(x[a:e]), (1, 1, 1, 1), mode="reflect"), wr[i], br[i]) for a, e, i in parts])
+    y2.backward(bf(dy))
+    for l, w_, b_ in zip(ls, wr, br):
+        assert (l.weight.grad.cpu() - w_.grad).abs().max() <= 1.6e-2 * float(w_.grad.abs().max())
+        assert (l.bias.grad.cpu() - b_.grad).abs().max() <= 3.2e-2 * float(b_.grad.abs().max())
+
+
+def test_train_step_fp8_tracks_bf16_and_graph_equals_eager():
+    """configs[4] as a step: CycleGAN(fp8=True) (ResBlock convs fwd + dgrad on MX fp8) at 128x128, batch 2: losses finite, within
+    6 % of the bf16 step on the same weights and inputs at step 0 (stated: two lossy 3-bit-mantissa roundings per ResBlock conv
+    against one bf16 rounding), and graph replay bitwise equal to eager launches."""
+    u, ops, networks = _mods()
+    torch.manual_seed(21)
+    rA, rB = (torch.rand(2, 3, 128, 128, device="cuda") * 2 - 1 for _ in range(2))
+    torch.manual_seed(5)
+    mb = u.CycleGAN(n_blocks=6, dtype=torch.bfloat16)
+    me = u.CycleGAN(n_blocks=6, dtype=torch.bfloat16, fp8=True)
+    mg = u.CycleGAN(n_blocks=6, dtype=torch.bfloat16, fp8=True, use_graph=True)
+    for m in (me, mg):
+        m.load_state_dicts(*[n.state_dict() for n in mb.nets()])
+    assert me.G_A[10].b[1].mx_active(8, 32, 32)
+    lb, le, lg = mb.train_step(rA, rB), me.train_step(rA, rB), mg.train_step(rA, rB)
+    print({k: (round(lb[k], 4), round(le[k], 4)) for k in lb})
+    for k in lb:
+        assert le[k] == le[k] and abs(le[k] - lb[k]) <= 6e-2 * max(1.0, abs(lb[k])), (k, lb[k], le[k])
+    assert le == lg
+    for _ in range(2):
+        le, lg = me.train_step(rA, rB), mg.train_step(rA, rB)
+        assert le == lg and all(v == v for v in le.values())
+    assert torch.equal(me.grp_G.flat, mg.grp_G.flat)
+    mg.close(); me.close(); mb.close()

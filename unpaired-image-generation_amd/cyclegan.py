@@ -34,10 +34,13 @@ LOSS_NAMES = ("idt_A", "idt_B", "G_A", "G_B", "cyc_A", "cyc_B", "D_A", "D_B")
 class CycleGAN:
     def __init__(self, n_blocks=9, dtype=torch.bfloat16, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-8,
                  lambda_cyc=10.0, lambda_idt=0.5, device="cuda", process_group=None, use_graph=False, batch_fused=True, paired=True,
-                 force_exchange=False, pool_size=0, pool_seed=0, stage_backward=None):
-        self.device, self.dtype = torch.device(device), dtype
+                 force_exchange=False, pool_size=0, pool_seed=0, stage_backward=None, fp8=False):
+        """fp8=True (with dtype bf16): mixed-precision step of BASELINE configs[4] - the generators' ResBlock convolutions run
+        forward and input gradient on the MX block-scaled fp8 MFMA kernel; everything else, the weight gradients and the
+        fp32 master weights / Adam are unchanged."""
+        self.device, self.dtype, self.fp8 = torch.device(device), dtype, bool(fp8)
         kw = dict(dtype=dtype, device=device)
-        self.G_A, self.G_B = Generator(n_blocks=n_blocks, **kw), Generator(n_blocks=n_blocks, **kw)
+        self.G_A, self.G_B = Generator(n_blocks=n_blocks, fp8=fp8, **kw), Generator(n_blocks=n_blocks, fp8=fp8, **kw)
         self.D_A, self.D_B = Discriminator(**kw), Discriminator(**kw)
         self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
         self.lr_scale = 1.0                               # LR-schedule multiplier (set_lr_scale / set_epoch)

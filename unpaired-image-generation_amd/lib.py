@@ -35,6 +35,9 @@ SIGNATURES = {
     "uig_reflect3x3_dgrad_border": (_i, [_vp, _vp, _vp, _i, _vp] + [_i] * 7 + [_vp]),
     "uig_conv_strip_applicable": (_i, [_i] * 10),
     "uig_conv_strip_tile": (_i, [_i] * 10),
+    "uig_conv3x3_mx_fp8_applicable": (_i, [_i] * 5),
+    "uig_conv3x3_mx_fp8": (_i, [_vp] * 8 + [_i] + [_vp] * 4 + [_i] * 8 + [_i, _f, _vp]),
+    "uig_mx_quantize": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "uig_wgrad_workspace_bytes": (_sz, [_i] * 5),
     "uig_wgrad_tile_rows": (_i, [_i, _i, _i]),
     "uig_debug_set_wgrad_wide": (None, [_i]),

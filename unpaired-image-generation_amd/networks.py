@@ -47,9 +47,36 @@ class ConvLayer(nn.Module):
         self._packed_version = None
         self.fuse_grad_accum = True    # backward adds dW/db into an existing .grad in place (see ops.ConvFn.backward)
         self.emit_in_stats = False     # set by the network builders for convs that feed an InstanceNorm
+        self.fp8 = False               # enable_fp8(): forward + input gradient on the MX block-scaled fp8 kernel
+
+    def enable_fp8(self):
+        """Run this layer's forward and input gradient on the MX block-scaled fp8 MFMA kernel (BASELINE configs[4]): e4m3
+        operands with one power-of-two scale per 32 channels, fp32 accumulate, bf16 activations, fp32 master weights; the
+        weight gradient stays on the bf16 path.  Only 3x3 stride-1 pad-1 convs with 128-multiples of channels (the ResBlocks)."""
+        s = self.spec
+        if self.compute_dtype != torch.bfloat16 or not (s.kind == "conv" and s.k == 3 and s.stride == 1 and s.pad == 1
+                                                        and s.cin % 128 == 0 and s.cout % 128 == 0 and s.act == L.ACT_NONE):
+            raise ValueError(f"enable_fp8: unsupported layer ({self.extra_repr()}, {self.compute_dtype})")
+        dev, t = self.weight.device, s.k * s.k
+        for name, rows, cols in (("fwd", s.cout, s.cin), ("dgrad", s.cin, s.cout)):
+            self.register_buffer("wq_" + name, torch.zeros((rows, t, cols), device=dev, dtype=torch.uint8), persistent=False)
+            self.register_buffer("ws_" + name, torch.zeros((rows, t, cols // 32), device=dev, dtype=torch.uint8), persistent=False)
+        self.fp8 = True
+        self._packed_version = None
+
+    def quantize_packed(self):
+        """fp8 operands from the packed bf16 operands: [rows * taps][cols] matrices quantised along cols"""
+        for wp, wq, ws in ((self.wp_fwd, self.wq_fwd, self.ws_fwd), (self.wp_dgrad, self.wq_dgrad, self.ws_dgrad)):
+            L.check(L.lib().uig_mx_quantize(wp.data_ptr(), wq.data_ptr(), ws.data_ptr(), wp.shape[0] * wp.shape[1], wp.shape[2],
+                                            L.BF16, torch.cuda.current_stream().cuda_stream), "uig_mx_quantize")
+
+    def mx_active(self, B, H, W) -> bool:
+        return self.fp8 and ops.mx_applicable(self.spec, B, H, W)
 
     def repack(self):
         ops.pack_weights(self.spec, self.weight.data, self.compute_dtype, self.wp_fwd, self.wp_dgrad)
+        if self.fp8:
+            self.quantize_packed()
         self._packed_version = self.weight._version
 
     def ensure_packed(self):
@@ -164,9 +191,10 @@ class _PhysNet(nn.Sequential):
 
 
 class Generator(_PhysNet):
-    """ResNet generator (Appendix A): c7s1-64, d128, d256, n_blocks x R256, u128, u64, c7s1-3 + tanh."""
+    """ResNet generator (Appendix A): c7s1-64, d128, d256, n_blocks x R256, u128, u64, c7s1-3 + tanh.
+    fp8=True: the ResBlock convolutions (88 % of the FLOPs) run forward and input gradient on the MX fp8 kernel."""
 
-    def __init__(self, in_ch=3, out_ch=3, ngf=64, n_blocks=9, dtype=torch.bfloat16, device="cuda"):
+    def __init__(self, in_ch=3, out_ch=3, ngf=64, n_blocks=9, dtype=torch.bfloat16, device="cuda", fp8=False):
         kw = dict(dtype=dtype, device=device)
         mods = [_Slot("ReflectionPad2d(3) -> conv gather"), ConvLayer("conv", in_ch, ngf, 7, 1, 3, "reflect", **kw),
                 InstNormAct(L.ACT_RELU), _Slot("ReLU -> instnorm"),
@@ -180,6 +208,10 @@ class Generator(_PhysNet):
         super().__init__(*mods)
         self.in_ch, self.out_ch, self.compute_dtype = in_ch, out_ch, dtype
         self._mark_in_producers()
+        if fp8:
+            for m in self:
+                if isinstance(m, ResBlock):
+                    m.b[1].enable_fp8(); m.b[5].enable_fp8()
 
 
 class Discriminator(_PhysNet):

@@ -204,6 +204,8 @@ class MultiPacker:
         L.check(L.lib().uig_pack_weights_multi(_p(self.items), self.n, self.total, dt, _stream()), "uig_pack_weights_multi")
         for l in self.layers:
             l._packed_version = l.weight._version
+            if l.fp8:
+                l.quantize_packed()
 
 
 def packed_shapes(spec: ConvSpec):
@@ -230,6 +232,34 @@ def _gather(x, wp, bias, y, B, H, W, C, nrows, spec, stride, pad, pm, mode, Ho, 
     L.check(rc, what)
 
 
+def mx_quantize(t: torch.Tensor):
+    """MX block-scaled fp8 (BASELINE configs[4]): contiguous (..., C) bf16 / f32 tensor, C % 32 == 0 -> (q uint8 (..., C) e4m3
+    bytes, s uint8 (..., C/32) E8M0 scale bytes), quantised along the last axis in blocks of 32 (uig_mx_quantize)."""
+    if not (t.is_cuda and t.is_contiguous() and t.shape[-1] % 32 == 0):
+        raise ValueError(f"mx_quantize: expected a contiguous CUDA tensor with C % 32 == 0, got {tuple(t.shape)}")
+    C = t.shape[-1]
+    q = torch.empty(t.shape, device=t.device, dtype=torch.uint8)
+    s = torch.empty(t.shape[:-1] + (C // 32,), device=t.device, dtype=torch.uint8)
+    L.check(L.lib().uig_mx_quantize(_p(t), _p(q), _p(s), t.numel() // C, C, _dt(t), _stream()), "uig_mx_quantize")
+    return q, s
+
+
+def mx_applicable(spec: ConvSpec, B: int, H: int, W: int) -> bool:
+    """can this layer's forward / input gradient run on the MX fp8 kernel? (3x3 stride-1 pad-1 conv, 128-multiples of channels)"""
+    return (spec.kind == "conv" and spec.k == 3 and spec.stride == 1 and spec.pad == 1 and spec.act == L.ACT_NONE
+            and spec.cin_p == spec.cin and spec.cout_p == spec.cout
+            and L.lib().uig_conv3x3_mx_fp8_applicable(B, H, W, spec.cin, spec.cout) == 1)
+
+
+def _conv3x3_mx(xq, xs, mx, bias, pair_bias, group, y, nrows, pad_mode, gather_mode, act, slope, in_partial=None, border_add=None, res_add=None):
+    """one uig_conv3x3_mx_fp8 launch; mx = (wq, ws) or (wq, ws, wq2, ws2) for a paired launch"""
+    B, H, W, C = xq.shape
+    wq2, ws2 = (mx[2], mx[3]) if len(mx) == 4 else (None, None)
+    L.check(L.lib().uig_conv3x3_mx_fp8(_p(xq), _p(xs), _p(mx[0]), _p(mx[1]), _p(bias), _p(wq2), _p(ws2), _p(pair_bias), group,
+                                       _p(in_partial), _p(border_add), _p(res_add), _p(y), B, H, W, C, nrows, pad_mode, gather_mode,
+                                       y.shape[3], act, slope, _stream()), "uig_conv3x3_mx_fp8")
+
+
 def in_stats_fusable(spec: ConvSpec, H: int, W: int, B: int = 1, dtype: torch.dtype = torch.bfloat16) -> bool:
     """can this layer's forward launch also emit the statistics of the InstanceNorm that follows it? (rule of uig_conv_gather_ex)"""
     Ho, Wo = spec.out_hw(H, W)
@@ -244,9 +274,10 @@ def in_stats_fusable(spec: ConvSpec, H: int, W: int, B: int = 1, dtype: torch.dt
 
 
 def conv_forward(spec: ConvSpec, x: torch.Tensor, wp_fwd: torch.Tensor, bias: torch.Tensor | None, pair=None,
-                 want_in_stats: bool = False) -> torch.Tensor:
+                 want_in_stats: bool = False, mx=None) -> torch.Tensor:
     """want_in_stats: also accumulate the following InstanceNorm's (sum, sum^2) partials in the epilogue; they travel to
-    ops.InstNormActFn as the attribute `_uig_in_partial` of the returned tensor."""
+    ops.InstNormActFn as the attribute `_uig_in_partial` of the returned tensor.
+    mx = (wq, ws[, wq2, ws2]): run the layer on the MX block-scaled fp8 kernel (x is quantised here, the output stays bf16)."""
     _chk_phys(x, "conv_forward")
     B, H, W, C = x.shape
     if C != spec.cin_p:
@@ -261,8 +292,13 @@ def conv_forward(spec: ConvSpec, x: torch.Tensor, wp_fwd: torch.Tensor, bias: to
     if want_in_stats and in_stats_fusable(spec, H, W, B, x.dtype):
         nslab = Ho * Wo // 64
         part = torch.empty((B * nslab * spec.cout_store * 2,), device=x.device, dtype=torch.float32)
-    _gather(x, wp_fwd, bias, y, B, H, W, C, spec.cout, spec, spec.stride, spec.pad, pm, mode, Ho, Wo, spec.cout_store,
-            spec.act, spec.slope, "uig_conv_gather(fwd)", pair, part)
+    if mx is not None:
+        xq, xs = mx_quantize(x)
+        _conv3x3_mx(xq, xs, mx, bias, pair[1] if pair is not None else None, pair[2] if pair is not None else 0, y, spec.cout, pm, mode,
+                    spec.act, spec.slope, part)
+    else:
+        _gather(x, wp_fwd, bias, y, B, H, W, C, spec.cout, spec, spec.stride, spec.pad, pm, mode, Ho, Wo, spec.cout_store,
+                spec.act, spec.slope, "uig_conv_gather(fwd)", pair, part)
     if part is not None:
         y._uig_in_partial = (part, Ho * Wo // 64)
     return y
@@ -276,7 +312,7 @@ def _dy_padded(spec: ConvSpec, dy: torch.Tensor) -> torch.Tensor:
     return to_nhwc(dy.permute(0, 3, 1, 2), dy.dtype, spec.cout_p)
 
 
-def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, pair=None, res_add=None) -> torch.Tensor:
+def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, pair=None, res_add=None, mx=None) -> torch.Tensor:
     """aten::convolution_backward, input gradient.  dy: (B,Ho,Wo,cout_p).  pair = (wp_dgrad2, None, group_images).
     res_add: a second gradient of the input (the ResBlock skip path's) to be summed in: fused into the launch's epilogue
     where the kernel supports it, one in-place add otherwise."""
@@ -289,7 +325,7 @@ def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, 
                    and tuple(res_add.shape) == (B, H, W, spec.cin_p)
                    and L.lib().uig_conv_strip_applicable(B, Ho, Wo, Cd, spec.cin, H, W, -1, 1, _dt(dy)) == 1)
         if not fusable:
-            dx = conv_dgrad(spec, dy, wp_dgrad, in_hw, pair)
+            dx = conv_dgrad(spec, dy, wp_dgrad, in_hw, pair, mx=mx)
             return dx.add_(res_add)
     if spec.kind == "convT":     # gradient of a transposed conv = strided direct conv of dy
         dx = torch.empty((B, H, W, spec.cin_p), device=dy.device, dtype=dy.dtype)
@@ -307,8 +343,13 @@ def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, 
         L.check(lib.uig_reflect3x3_dgrad_border(_p(dy), _p(wp_dgrad), _p(wp2), g, _p(bord), B, Ho, Wo, Cd, spec.cin, spec.cin_p,
                                                 _dt(dy), s), "uig_reflect3x3_dgrad_border")
         dx = torch.empty((B, H, W, spec.cin_p), device=dy.device, dtype=dy.dtype)
-        _gather(dy, wp_dgrad, None, dx, B, Ho, Wo, Cd, spec.cin, spec, 1, 1, L.PAD_ZERO, L.GATHER_TRANSPOSED, H, W, spec.cin_p,
-                L.ACT_NONE, 0.0, "uig_conv_gather(dgrad+border)", pair, None, bord, res_add)
+        if mx is not None:       # main term on the MX fp8 kernel (dy quantised here); the mirrored-border GEMM above stays bf16
+            dq, ds = mx_quantize(dy)
+            _conv3x3_mx(dq, ds, mx, None, None, pair[2] if pair is not None else 0, dx, spec.cin, L.PAD_ZERO, L.GATHER_TRANSPOSED,
+                        L.ACT_NONE, 0.0, None, bord, res_add)
+        else:
+            _gather(dy, wp_dgrad, None, dx, B, Ho, Wo, Cd, spec.cin, spec, 1, 1, L.PAD_ZERO, L.GATHER_TRANSPOSED, H, W, spec.cin_p,
+                    L.ACT_NONE, 0.0, "uig_conv_gather(dgrad+border)", pair, None, bord, res_add)
         return dx
     if spec.reflect:             # gradient w.r.t. the reflection-padded input, then fold the border back
         P = spec.pad
@@ -491,6 +532,9 @@ def _conv_backward(ctx, dy, layers, group):
     need_b = [ctx.needs_input_grad[2 + 2 * i] for i in range(npar)]
     any_p = any(need_w) or any(need_b)
     pair = None if npar == 1 else (layers[1].wp_dgrad, None, group)
+    mx = None
+    if all(l.mx_active(dy.shape[0], ctx.in_hw[0], ctx.in_hw[1]) for l in layers):
+        mx = sum(((l.wq_dgrad, l.ws_dgrad) for l in layers), ())
     fused_all = all(l.fuse_grad_accum and l.weight.grad is not None and l.bias.grad is not None for l in layers)
     defer = _DEFER_JOIN.get(torch.device(dy.device).index, False) and any_p and fused_all and PARALLEL_BACKWARD
     par = (need_x or defer) and any_p and PARALLEL_BACKWARD
@@ -501,7 +545,7 @@ def _conv_backward(ctx, dy, layers, group):
         skip, link.grad = link.grad, None
     dx = None
     if need_x and not par:
-        dx = conv_dgrad(spec, dy, layers[0].wp_dgrad, ctx.in_hw, pair, skip)
+        dx = conv_dgrad(spec, dy, layers[0].wp_dgrad, ctx.in_hw, pair, skip, mx=mx)
     grads = []
     if par:
         side = _side_stream(dy.device)
@@ -520,7 +564,7 @@ def _conv_backward(ctx, dy, layers, group):
             grads.extend(_param_grads(layer, spec, xs, dys, need_w[i], need_b[i], colsum, i0, pparts[i] if pparts else None))
     if par:
         if need_x:
-            dx = conv_dgrad(spec, dy, layers[0].wp_dgrad, ctx.in_hw, pair, skip)
+            dx = conv_dgrad(spec, dy, layers[0].wp_dgrad, ctx.in_hw, pair, skip, mx=mx)
         if defer:
             # no join here: the side stream keeps working behind the main stream's next ops (InstanceNorm backward, the next
             # layer's input gradient, ...).  The tensors it reads are pinned for the allocator with record_stream; the owner
@@ -541,7 +585,8 @@ class ConvFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, layer, skip_link=None):
         spec = layer.spec
-        y = conv_forward(spec, x, layer.wp_fwd, bias, want_in_stats=layer.emit_in_stats)
+        mx = (layer.wq_fwd, layer.ws_fwd) if layer.mx_active(x.shape[0], x.shape[1], x.shape[2]) else None
+        y = conv_forward(spec, x, layer.wp_fwd, bias, want_in_stats=layer.emit_in_stats, mx=mx)
         ctx.layer, ctx.in_hw, ctx.skip_link = layer, (x.shape[1], x.shape[2]), skip_link
         ctx.save_for_backward(x, y if spec.act != L.ACT_NONE else None)
         return y
@@ -559,7 +604,10 @@ class PairConvFn(Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, layer1, layer2, group, skip_link=None):
         spec = layer1.spec
-        y = conv_forward(spec, x, layer1.wp_fwd, b1, pair=(layer2.wp_fwd, b2, group), want_in_stats=layer1.emit_in_stats)
+        mx = None
+        if layer1.mx_active(x.shape[0], x.shape[1], x.shape[2]) and layer2.mx_active(x.shape[0], x.shape[1], x.shape[2]):
+            mx = (layer1.wq_fwd, layer1.ws_fwd, layer2.wq_fwd, layer2.ws_fwd)
+        y = conv_forward(spec, x, layer1.wp_fwd, b1, pair=(layer2.wp_fwd, b2, group), want_in_stats=layer1.emit_in_stats, mx=mx)
         ctx.layers, ctx.group, ctx.in_hw, ctx.skip_link = (layer1, layer2), group, (x.shape[1], x.shape[2]), skip_link
         ctx.save_for_backward(x, y if spec.act != L.ACT_NONE else None)
         return y
