@@ -189,7 +189,7 @@ def dominant_kernel_roofline(u, torch, dev, dtype, nimg, hw, iters, fp8=False):
     e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (2 * iters)
     flops = 2.0 * nimg * hw * hw * 256 * 2304
-    peak = PEAK_BF16 if dtype == torch.bfloat16 else PEAK_F32
+    peak = PEAK_FP8 if fp8 else (PEAK_BF16 if dtype == torch.bfloat16 else PEAK_F32)
     ach = flops / (us * 1e-6)
     # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs,
     # gfx950 FETCH_SIZE x2 correction: scripts/prof_dominant.sh + scripts/pmc_summary.py); null when the shape differs.

@@ -186,6 +186,12 @@ int uig_instnorm_act_fwd(const void* x, const void* residual, void* y, float* st
 /* the same forward with the statistics partials already produced by uig_conv_gather_ex (nslab = HW/64 per image) */
 int uig_instnorm_act_fwd_pre(const void* x, const void* residual, void* y, float* stats, const float* partial, int nslab,
                              int B, int64_t HW, int C, float eps, int act, float slope, int dtype, void* stream);
+/* Inference form (no autograd state: nothing is saved for a backward pass): the apply kernel finalises the statistics
+ * itself.  partial != NULL: the np-per-image epilogue partials of uig_conv_gather_ex -> ONE launch; partial == NULL: a
+ * statistics pass into workspace (uig_instnorm_workspace_floats), then the fused apply.  Bit-identical to
+ * uig_instnorm_act_fwd[_pre] (same fp64 association order). */
+int uig_instnorm_act_fwd_infer(const void* x, const void* residual, void* y, const float* partial, int np, float* workspace,
+                               int B, int64_t HW, int C, float eps, int act, float slope, int dtype, void* stream);
 /* aten::native_batch_norm_backward (on the (1,B*C,H,W) view) fused with the activation's backward:
  *   g = dy * act'(xhat);  dx = rstd * (g - mean(g) - xhat * mean(g*xhat))                                   */
 int uig_instnorm_act_bwd(const void* dy, const void* x, const float* stats, void* dx, float* workspace,

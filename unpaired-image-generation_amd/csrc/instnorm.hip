@@ -122,6 +122,67 @@ __global__ __launch_bounds__(256) void in_apply_fwd_kernel(const T* __restrict__
     }
 }
 
+// Inference form (InstanceNorm fused for latency): the apply kernel FINALISES the statistics itself,
+// so an InstanceNorm behind a convolution that emitted the partials in its epilogue is ONE launch instead of two (finalize +
+// apply), and no (mean, rstd) tensor is written: nothing is kept for a backward pass.  Phase 1: thread c of the block
+// reduces channel c's `np` partial (sum, sum^2) pairs in fp64 - in exactly the association order of in_finalize_kernel (16
+// strided accumulators, then the xor-shuffle tree), so the result is bit-identical to the three-launch path - and leaves
+// (mean, rstd) in LDS; phase 2 is in_apply_fwd_kernel.  Each block re-reads the image's partials (np * C * 8 bytes, L2
+// resident): that is what makes this slower than the separate finalize launch at training batch sizes (measured in round 1:
+// 21.7 vs 16.4 us at batch 16) and faster on the batch-1 dependent chain of a single image, where every launch boundary counts.
+template <typename T>
+__global__ __launch_bounds__(256) void in_apply_fwd_fin_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                                               const float* __restrict__ partial, int np, double inv_n, float eps,
+                                                               long HW, int C, int CC, int nslab, int act, float slope) {
+    constexpr int E = ElemTraits<T>::E;
+    __shared__ float st[2048 * 2];                        // C <= 2048 (CC <= 256)
+    const int tid = threadIdx.x, b = blockIdx.y;
+    for (int c = tid; c < C; c += 256) {
+        double a16[16], q16[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a16[i] = 0.0; q16[i] = 0.0; }
+        for (int s0 = 0; s0 < np; s0 += 16) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (s0 + i < np) {
+                    const float* pp = partial + (((long)b * np + s0 + i) * C + c) * 2;
+                    a16[i] += (double)pp[0]; q16[i] += (double)pp[1];
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if ((i & o) == 0 && i < o) { a16[i] += a16[i ^ o]; q16[i] += q16[i ^ o]; }
+        const double mean = a16[0] * inv_n;
+        double var = q16[0] * inv_n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        st[2 * c] = (float)mean; st[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int PL = 256 / CC, pl = tid / CC, cc = tid % CC;
+    const long sp = (HW + nslab - 1) / nslab;
+    const long p0 = blockIdx.x * sp, p1 = min(HW, p0 + sp);
+    const long base = (long)b * HW * C + cc * E;
+    float mu[E], rs[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { mu[e] = st[2 * (cc * E + e)]; rs[e] = st[2 * (cc * E + e) + 1]; }
+    for (long p = p0 + pl; p < p1; p += PL) {
+        float v[E];
+        chunk_to_f32<T>(*reinterpret_cast<const u32x4_t*>(x + base + p * C), v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = apply_act((v[e] - mu[e]) * rs[e], act, slope);
+        if (res != nullptr) {
+            float r[E];
+            chunk_to_f32<T>(*reinterpret_cast<const u32x4_t*>(res + base + p * C), r);
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] += r[e];
+        }
+        *reinterpret_cast<u32x4_t*>(y + base + p * C) = f32_to_chunk<T>(v);
+    }
+}
+
 // COLSUM: additionally emit per-block partial sums of the written dx (as stored, i.e. after rounding to T) per channel:
 // the bias gradient of the convolution in front of this InstanceNorm is the column sum of exactly this tensor, so the
 // separate full read pass of uig_bias_grad disappears (it sat on the backward critical path).
@@ -308,5 +369,33 @@ extern "C" int uig_bias_grad(const void* dy, float* db, float* workspace, int64_
     UIG_LAUNCH_CHECK("uig_bias_grad(partial)");
     hipLaunchKernelGGL(in_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, workspace, db, C, C, ns, 1.0, 0.f, 2, Nreal, accumulate);
     UIG_LAUNCH_CHECK("uig_bias_grad(finalize)");
+    return 0;
+}
+
+// Inference forward (no statistics kept): partial != NULL -> the producing convolution's epilogue partials (np per image), ONE
+// launch; partial == NULL -> statistics pass into `workspace`, then the fused apply: two launches instead of three.
+extern "C" int uig_instnorm_act_fwd_infer(const void* x, const void* residual, void* y, const float* partial, int np, float* workspace,
+                                          int B, int64_t HW, int C, float eps, int act, float slope, int dtype, void* stream) {
+    UIG_CHECK_ARG(x && y && (partial || workspace), "uig_instnorm_act_fwd_infer: null pointer");
+    UIG_CHECK_ARG(act == UIG_ACT_NONE || act == UIG_ACT_RELU || act == UIG_ACT_LRELU, "uig_instnorm_act_fwd_infer: bad act %d", act);
+    int CC; if (int r = check_in_args("uig_instnorm_act_fwd_infer", B, HW, C, dtype, &CC)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    if (partial == nullptr) {
+        np = stats_slabs(HW, CC);
+        if (dtype == UIG_BF16)
+            hipLaunchKernelGGL((in_stats_kernel<bf16_t, 0>), dim3(np, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, workspace, (long)HW, C, CC, np, 0, 0.f);
+        else
+            hipLaunchKernelGGL((in_stats_kernel<float, 0>), dim3(np, B), dim3(256), 0, s, (const float*)x, (const float*)nullptr, (const float*)nullptr, workspace, (long)HW, C, CC, np, 0, 0.f);
+        UIG_LAUNCH_CHECK("uig_instnorm_act_fwd_infer(stats)");
+        partial = workspace;
+    }
+    UIG_CHECK_ARG(np > 0, "uig_instnorm_act_fwd_infer: np=%d", np);
+    // fewer, fatter blocks than the training apply: every block pays the np * C * 8-byte finalize prologue
+    const int na = (int)std::max<long>(1, std::min<long>(256, HW * CC / (256 * 16)));
+    if (dtype == UIG_BF16)
+        hipLaunchKernelGGL((in_apply_fwd_fin_kernel<bf16_t>), dim3(na, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, partial, np, 1.0 / (double)HW, eps, (long)HW, C, CC, na, act, slope);
+    else
+        hipLaunchKernelGGL((in_apply_fwd_fin_kernel<float>), dim3(na, B), dim3(256), 0, s, (const float*)x, (const float*)residual, (float*)y, partial, np, 1.0 / (double)HW, eps, (long)HW, C, CC, na, act, slope);
+    UIG_LAUNCH_CHECK("uig_instnorm_act_fwd_infer(apply)");
     return 0;
 }

@@ -62,6 +62,7 @@ SIGNATURES = {
     "uig_instnorm_workspace_floats": (_sz, [_i, _i64, _i]),
     "uig_instnorm_act_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _i, _f, _i, _vp]),
     "uig_instnorm_act_fwd_pre": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _f, _i, _f, _i, _vp]),
+    "uig_instnorm_act_fwd_infer": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, _f, _i, _f, _i, _vp]),
     "uig_instnorm_act_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _vp]),
     "uig_instnorm_bwd_colsum_slabs": (_i, [_i, _i64, _i, _i]),
     "uig_instnorm_act_bwd_colsum": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _vp]),

@@ -100,6 +100,8 @@ class InstNormAct(nn.Module):
         self.act, self.slope, self.eps = act, slope, eps
 
     def forward(self, x, residual=None, skip_link=None):
+        if ops.INFER_FUSED_IN and not torch.is_grad_enabled() and ops.instnorm_infer_applicable(x):      # inference: no statistics kept, finalize fused into the apply launch
+            return ops.instnorm_infer(x, residual, self.act, self.slope, self.eps)
         return ops.InstNormActFn.apply(x, residual, self.act, self.slope, self.eps, skip_link)
 
 

@@ -618,6 +618,36 @@ class PairConvFn(Function):
 
 
 # ----------------------------------------------------------------------------------------- instance norm (+act, +residual)
+# no-grad forwards: InstanceNorm finalised inside its apply kernel (SURVEY §8(f) row 4's "fused IN for latency").  OFF by default:
+# measured on MI355X (scripts/bench_infer.py, G9 bf16, batch 1, 256x256, HIP graph) 1.371 ms with the 19 ResBlock norms fused
+# against 0.959 ms with the finalize + apply launches - the per-block re-read and fp64 reduction of the partials (64 x 256
+# channels) costs ~25 us per norm, a finalize launch ~5 us.  Kept as an opt-in, bit-identical to the training kernels (tested).
+INFER_FUSED_IN = os.environ.get("UIG_INFER_FUSED_IN", "0") != "0"
+
+
+def instnorm_infer(x, residual, act, slope, eps):
+    """InstanceNorm(+act, +residual) forward with no autograd state (inference): the statistics are
+    finalised inside the apply kernel - one launch behind a convolution that emitted the partials, two otherwise."""
+    _chk_phys(x, "instnorm")
+    B, H, W, C = x.shape
+    lib = L.lib()
+    y = torch.empty_like(x)
+    pre = getattr(x, "_uig_in_partial", None)
+    L.check(lib.uig_instnorm_act_fwd_infer(_p(x), _p(residual), _p(y), _p(pre[0]), pre[1], None, B, H * W, C, eps, act, slope,
+                                           _dt(x), _stream()), "uig_instnorm_act_fwd_infer")
+    return y
+
+
+INFER_FUSED_MAX_PARTIALS = int(os.environ.get("UIG_INFER_FUSED_MAX_PARTIALS", "64"))
+
+
+def instnorm_infer_applicable(x) -> bool:
+    """every block of the fused kernel re-reads the image's partial statistics (np * C * 8 bytes): only worth it for the small
+    maps of the ResBlocks (64 partials per image at 256x256), not for the 128^2 / 256^2 layers (256 / 1024 partials)"""
+    pre = getattr(x, "_uig_in_partial", None)
+    return pre is not None and pre[1] <= INFER_FUSED_MAX_PARTIALS and pre[0].numel() == x.shape[0] * pre[1] * x.shape[3] * 2
+
+
 class InstNormActFn(Function):
     @staticmethod
     def forward(ctx, x, residual, act, slope, eps, skip_link=None):
