@@ -107,6 +107,15 @@ int uig_conv3x3_mx_fp8(const void* xq, const void* xs, const void* wq, const voi
                        float* in_partial, const void* border_add, const void* res_add, void* y,
                        int B, int H, int W, int Cin, int Nrows, int pad_mode, int gather_mode, int ldc,
                        int act, float slope, void* stream);
+/* InstanceNorm forward / backward that ALSO emit the MX fp8 form (mx_q [B*HW][C] e4m3, mx_s [B*HW][C/32] E8M0) of exactly the
+ * bf16 tensor they write - the operand of the fp8 convolution that consumes it, without the stand-alone quantiser's extra pass.
+ * fwd: partial != NULL as uig_instnorm_act_fwd_pre, else as uig_instnorm_act_fwd (workspace).  bf16, C a multiple of 32. */
+int uig_instnorm_act_fwd_mx(const void* x, const void* residual, void* y, float* stats, const float* partial, int nslab,
+                            float* workspace, void* mx_q, void* mx_s,
+                            int B, int64_t HW, int C, float eps, int act, float slope, int dtype, void* stream);
+int uig_instnorm_act_bwd_colsum_mx(const void* dy, const void* x, const float* stats, void* dx, float* workspace,
+                                   float* colsum_partial, void* mx_q, void* mx_s, int B, int64_t HW, int C, int act, float slope,
+                                   int dtype, void* stream);
 /* MX quantisation along the last axis of a [P][C] matrix (dtype UIG_F32 / UIG_BF16), C a multiple of 32: per block of 32,
  * scale = 2^(floor(log2(max|x|)) - 8) as an E8M0 byte (127 for an all-zero block), elements = RNE(x / scale) in e4m3,
  * saturated to +-448.  q: [P][C] bytes, scales: [P][C/32] bytes. */

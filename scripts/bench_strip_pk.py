@@ -17,7 +17,7 @@ def t(fn, n=40):
     e0.record()
     for _ in range(n): fn()
     e1.record(); e1.synchronize(); return e0.elapsed_time(e1) * 1e3 / n
-VARIANTS = {"tile/block": (3, 0, 0), "pk rot+lgk": (1, 0, 0), "pk xor+lgk": (1, 2, 0), "pk rot": (1, 4, 0), "pk xor": (1, 6, 0)}
+VARIANTS = {"tile/block": (3, 0, 0), "pk": (1, 0, 0), "pk nolgk": (1, 4, 0), "pk rd0-dma": (1, 8, 0), "pk rdall-dma": (1, 9, 0), "pk setprio": (1, 10, 0)}
 if len(sys.argv) > 1:
     VARIANTS.update({f"pk rot g{g}": (1, 4, int(g)) for g in sys.argv[1:]})
 def select(v):

@@ -10,7 +10,7 @@ for name in ("fetch", "write", "sq"):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
-        if "conv_strip_kernel" in r["Kernel_Name"] or "igemm_kernel" in r["Kernel_Name"]:
+        if "conv_strip" in r["Kernel_Name"] or "igemm_kernel" in r["Kernel_Name"]:
             res["kernel"] = r["Kernel_Name"].split("(")[0]
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
@@ -18,7 +18,7 @@ for name in ("fetch", "write", "sq"):
 st = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")
 if st:
     for r in csv.DictReader(open(st[0])):
-        if "conv_strip_kernel" in r["Name"] or "igemm_kernel" in r["Name"]:
+        if "conv_strip" in r["Name"] or "igemm_kernel" in r["Name"]:
             res["avg_duration_us"] = float(r["AverageNs"]) / 1e3; res["calls"] = int(r["Calls"])
 if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
     res["hbm_read_bytes_corrected"] = res["FETCH_SIZE"] * 1024 * 2

@@ -131,3 +131,28 @@ def test_train_step_fp8_tracks_bf16_and_graph_equals_eager():
         assert le == lg and all(v == v for v in le.values())
     assert torch.equal(me.grp_G.flat, mg.grp_G.flat)
     mg.close(); me.close(); mb.close()
+
+
+def test_fused_mx_quantisation_equals_standalone_quantiser():
+    """The fp8 step with the MX quantisation fused into the InstanceNorm launches (forward: the norm in front of each fp8 conv;
+    backward: the norm whose dx is the conv's dy) against the same step with stand-alone quantiser passes: the fused epilogue
+    quantises exactly the bf16 values it stores with the same device function, so the steps agree bit for bit."""
+    u, ops, networks = _mods()
+    torch.manual_seed(33)
+    rA, rB = (torch.rand(2, 3, 128, 128, device="cuda") * 2 - 1 for _ in range(2))
+    old = ops.FUSE_MX_QUANT
+    try:
+        ops.FUSE_MX_QUANT = True
+        torch.manual_seed(5)
+        mf = u.CycleGAN(n_blocks=3, dtype=torch.bfloat16, fp8=True)
+        ops.FUSE_MX_QUANT = False
+        ms = u.CycleGAN(n_blocks=3, dtype=torch.bfloat16, fp8=True)
+    finally:
+        ops.FUSE_MX_QUANT = old
+    ms.load_state_dicts(*[n.state_dict() for n in mf.nets()])
+    assert mf.G_A[10].b[2].mx_fwd and mf.G_A[10].b[6].mx_bwd and mf.G_A[8].mx_fwd and not ms.G_A[10].b[2].mx_fwd
+    for step in range(2):
+        lf, ls = mf.train_step(rA, rB), ms.train_step(rA, rB)
+        assert lf == ls, (step, lf, ls)
+    assert torch.equal(mf.grp_G.flat, ms.grp_G.flat)
+    mf.close(); ms.close()

@@ -355,28 +355,10 @@ __global__ void mx_quantize_kernel(const T* __restrict__ x, unsigned char* __res
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = 0.f;
     }
-    float am = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(f[e]));
-    am = fmaxf(am, __shfl_xor(am, 1, 64));
-    am = fmaxf(am, __shfl_xor(am, 2, 64));
-    // shared exponent: floor(log2(amax)) - 8 (e4m3 emax); amax = 0 -> scale 1.0.  E8M0 byte = exponent + 127, clamped to [0, 254].
-    const int eb = (int)((__float_as_uint(am) >> 23) & 0xff);                  // biased exponent of amax (0 for zero / subnormal)
-    const int sb = am == 0.f ? 127 : min(max(eb - 8, 0), 254);
-    const float inv = __uint_as_float((unsigned)(254 - sb) << 23);              // 2^-(sb - 127): exact; sb = 254 -> 2^-127 is subnormal:
-    const float invs = sb == 254 ? 5.877471754111438e-39f : inv;               //   spelled out (the bit pattern above would be 0)
-    unsigned w[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(f[4 * h + e] * invs, -448.f), 448.f);
-        int p = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
-        p = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], p, true);
-        w[h] = (unsigned)p;
-    }
+    int sb;
+    const u32x2_t w = mx_quantize8(f, sb);
     if (ok) {
-        *reinterpret_cast<u32x2_t*>(q + 8 * i) = u32x2_t{w[0], w[1]};
+        *reinterpret_cast<u32x2_t*>(q + 8 * i) = w;
         if ((i & 3) == 0) s[i >> 2] = (unsigned char)sb;
     }
 }

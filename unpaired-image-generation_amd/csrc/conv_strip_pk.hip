@@ -204,8 +204,28 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                     if (which < 2) { if (w_on) issue_w1(which, w_g2, w_so, w_reg); }
                     else if (p_on) issue_strip_piece(slot, s_base, s_NS, pc ^ 1);
                 };
-                if constexpr (DM == 0) { dma(0); dma(1); dma(2); }
+                if constexpr (DM == 0 || DM == 4) { dma(0); dma(1); dma(2); }
                 const unsigned char* sw = smem + (pc ^ (t & 1)) * REG + SBUF + (wn * WN + l16) * 128;
+                if constexpr (DM == 3) {                        // all 16 fragment reads of the step first, then the DMAs, then 32 MFMAs
+                    u32x4_t xf[2][MT], wf[2][NT];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                        for (int b = 0; b < MT; ++b) xf[h][b] = *reinterpret_cast<const u32x4_t*>(sx + ((unsigned)rt[t][b] ^ (unsigned)(h << 6)));
+                        const int co = ((q + 4 * h) ^ wswz) << 4;
+#pragma unroll
+                        for (int a = 0; a < NT; ++a) wf[h][a] = *reinterpret_cast<const u32x4_t*>(sw + a * 16 * 128 + co);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    dma(0); dma(1); dma(2);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int a = 0; a < NT; ++a)
+#pragma unroll
+                            for (int b = 0; b < MT; ++b) MmaS<T>::run(wf[h][a], xf[h][b], acc[a][b]);
+                } else {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     u32x4_t xf[MT], wf[NT];
@@ -214,6 +234,8 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                     const int co = ((q + 4 * h) ^ wswz) << 4;
 #pragma unroll
                     for (int a = 0; a < NT; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(sw + a * 16 * 128 + co);
+                    if constexpr (DM == 2) { if (h == 0) { __builtin_amdgcn_sched_barrier(0); dma(0); dma(1); dma(2); __builtin_amdgcn_sched_barrier(0); } }
+                    if constexpr (DM == 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int a = 0; a < NT; ++a) {
 #pragma unroll
@@ -224,6 +246,8 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                             if (h == 1 && a == 0) { __builtin_amdgcn_sched_barrier(0); dma(2); __builtin_amdgcn_sched_barrier(0); }
                         }
                     }
+                    if constexpr (DM == 4) __builtin_amdgcn_s_setprio(0);
+                }
                 }
             }
         }
@@ -266,8 +290,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
     }
 }
 
-static int g_pk_dm = 0;        // tuning hook: variant of the bf16 kernel: bit 0 = DMA issue spread between MFMA groups, bit 1 = XOR swizzle,
-                               // bit 2 = no lgkmcnt wait before the K-step barrier
+static int g_pk_dm = 0;        // tuning hook: variant of the bf16 kernel (see the switch in uig_launch_strip_pk)
 static int g_pk_grid = 0;      // tuning hook: persistent grid size (0 = one block per CU)
 extern "C" void uig_debug_set_strip_pk(int dm, int grid) { g_pk_dm = dm; g_pk_grid = grid; }
 
@@ -310,11 +333,12 @@ int uig_launch_strip_pk(const void* x, const void* wp, const float* bias, void* 
     const int ntiles = d.B * tpi * (d.Nrows / 128);
     if (dtype == UIG_BF16) {
         if (d.dbg != nullptr) return launch_pk<bf16_t, 448, 0, 1, true, true>(x, wp, bias, y, d, ntiles, s);
-        switch (g_pk_dm) {
-            case 1: return launch_pk<bf16_t, 448, 1, 1, true>(x, wp, bias, y, d, ntiles, s);
-            case 2: return launch_pk<bf16_t, 448, 0, 0, true>(x, wp, bias, y, d, ntiles, s);
-            case 4: return launch_pk<bf16_t, 448, 0, 1, false>(x, wp, bias, y, d, ntiles, s);
-            case 6: return launch_pk<bf16_t, 448, 0, 0, false>(x, wp, bias, y, d, ntiles, s);
+        switch (g_pk_dm) {      // tuning variants (A/B in one process: scripts/bench_strip_pk.py)
+            case 2: return launch_pk<bf16_t, 448, 0, 0, true>(x, wp, bias, y, d, ntiles, s);      // XOR swizzle (for the bank-conflict counters)
+            case 4: return launch_pk<bf16_t, 448, 0, 1, false>(x, wp, bias, y, d, ntiles, s);     // no lgkmcnt wait before the barrier
+            case 8: return launch_pk<bf16_t, 448, 2, 1, false>(x, wp, bias, y, d, ntiles, s);     // reads of half 0, then the DMAs
+            case 9: return launch_pk<bf16_t, 448, 3, 1, false>(x, wp, bias, y, d, ntiles, s);     // all reads up front, then the DMAs
+            case 10: return launch_pk<bf16_t, 448, 4, 1, false>(x, wp, bias, y, d, ntiles, s);    // s_setprio around the MFMA clusters
             default: return launch_pk<bf16_t, 448, 0, 1, true>(x, wp, bias, y, d, ntiles, s);
         }
     }

@@ -96,7 +96,8 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void in_apply_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                             T* __restrict__ y, const float* __restrict__ stats,
-                                                            long HW, int C, int CC, int nslab, int act, float slope) {
+                                                            long HW, int C, int CC, int nslab, int act, float slope,
+                                                            unsigned char* __restrict__ mxq = nullptr, unsigned char* __restrict__ mxs = nullptr) {
     constexpr int E = ElemTraits<T>::E;
     const int tid = threadIdx.x;
     const int PL = 256 / CC, pl = tid / CC, cc = tid % CC;
@@ -118,7 +119,19 @@ __global__ __launch_bounds__(256) void in_apply_fwd_kernel(const T* __restrict__
 #pragma unroll
             for (int e = 0; e < E; ++e) v[e] += r[e];
         }
-        *reinterpret_cast<u32x4_t*>(y + base + p * C) = f32_to_chunk<T>(v);
+        const u32x4_t packed = f32_to_chunk<T>(v);
+        *reinterpret_cast<u32x4_t*>(y + base + p * C) = packed;
+        if constexpr (E == 8) {
+            if (mxq != nullptr) {      // also the MX fp8 form of the stored (bf16-rounded) values for the fp8 convolution that consumes them
+                float rv[E];
+                chunk_to_f32<T>(packed, rv);
+                int sb;
+                const u32x2_t w = mx_quantize8(rv, sb);
+                const long pix = (long)b * HW + p;
+                *reinterpret_cast<u32x2_t*>(mxq + pix * C + cc * 8) = w;
+                if ((cc & 3) == 0) mxs[pix * (C / 32) + (cc >> 2)] = (unsigned char)sb;
+            }
+        }
     }
 }
 
@@ -190,7 +203,8 @@ template <typename T, bool COLSUM>
 __global__ __launch_bounds__(256) void in_apply_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             T* __restrict__ dx, const float* __restrict__ stats,
                                                             const float* __restrict__ gm, float* __restrict__ colsum_partial,
-                                                            long HW, int C, int CC, int nslab, int act, float slope) {
+                                                            long HW, int C, int CC, int nslab, int act, float slope,
+                                                            unsigned char* __restrict__ mxq = nullptr, unsigned char* __restrict__ mxs = nullptr) {
     constexpr int E = ElemTraits<T>::E;
     __shared__ float red[COLSUM ? 256 * E : 1];
     const int tid = threadIdx.x;
@@ -224,6 +238,17 @@ __global__ __launch_bounds__(256) void in_apply_bwd_kernel(const T* __restrict__
             chunk_to_f32<T>(packed, rv);
 #pragma unroll
             for (int e = 0; e < E; ++e) cs[e] += rv[e];
+        }
+        if constexpr (E == 8) {
+            if (mxq != nullptr) {      // MX fp8 form of the stored dx: the input of the fp8 input-gradient convolution in front
+                float rv[E];
+                chunk_to_f32<T>(packed, rv);
+                int sb;
+                const u32x2_t w = mx_quantize8(rv, sb);
+                const long pix = (long)b * HW + p;
+                *reinterpret_cast<u32x2_t*>(mxq + pix * C + cc * 8) = w;
+                if ((cc & 3) == 0) mxs[pix * (C / 32) + (cc >> 2)] = (unsigned char)sb;
+            }
         }
     }
     if constexpr (COLSUM) {
@@ -288,7 +313,8 @@ extern "C" int uig_instnorm_bwd_colsum_slabs(int B, int64_t HW, int C, int dtype
 }
 
 static int instnorm_bwd_impl(const void* dy, const void* x, const float* stats, void* dx, float* workspace, float* colsum_partial,
-                             int B, int64_t HW, int C, int act, float slope, int dtype, void* stream) {
+                             int B, int64_t HW, int C, int act, float slope, int dtype, void* stream,
+                             unsigned char* mxq = nullptr, unsigned char* mxs = nullptr) {
     UIG_CHECK_ARG(dy && x && stats && dx && workspace, "uig_instnorm_act_bwd: null pointer");
     UIG_CHECK_ARG(act == UIG_ACT_NONE || act == UIG_ACT_RELU || act == UIG_ACT_LRELU, "uig_instnorm_act_bwd: bad act %d", act);
     int CC; if (int r = check_in_args("uig_instnorm_act_bwd", B, HW, C, dtype, &CC)) return r;
@@ -304,7 +330,7 @@ static int instnorm_bwd_impl(const void* dy, const void* x, const float* stats, 
     UIG_LAUNCH_CHECK("uig_instnorm_act_bwd(finalize)");
     if (colsum_partial) {
         if (dtype == UIG_BF16)
-            hipLaunchKernelGGL((in_apply_bwd_kernel<bf16_t, true>), dim3(na, B), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, stats, gm, colsum_partial, (long)HW, C, CC, na, act, slope);
+            hipLaunchKernelGGL((in_apply_bwd_kernel<bf16_t, true>), dim3(na, B), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, stats, gm, colsum_partial, (long)HW, C, CC, na, act, slope, mxq, mxs);
         else
             hipLaunchKernelGGL((in_apply_bwd_kernel<float, true>), dim3(na, B), dim3(256), 0, s, (const float*)dy, (const float*)x, (float*)dx, stats, gm, colsum_partial, (long)HW, C, CC, na, act, slope);
     } else {
@@ -398,4 +424,39 @@ extern "C" int uig_instnorm_act_fwd_infer(const void* x, const void* residual, v
         hipLaunchKernelGGL((in_apply_fwd_fin_kernel<float>), dim3(na, B), dim3(256), 0, s, (const float*)x, (const float*)residual, (float*)y, partial, np, 1.0 / (double)HW, eps, (long)HW, C, CC, na, act, slope);
     UIG_LAUNCH_CHECK("uig_instnorm_act_fwd_infer(apply)");
     return 0;
+}
+
+// ---- the same two launches with the MX fp8 form of their output as a second result (BASELINE configs[4]): mx_q [B*HW][C] e4m3
+// bytes + mx_s [B*HW][C/32] E8M0 bytes of exactly the bf16 values written to y / dx (uig_mx_quantize of that tensor, fused: the
+// stand-alone quantiser is a full extra read + write pass per fp8 convolution).  bf16 only, C a multiple of 32.
+extern "C" int uig_instnorm_act_fwd_mx(const void* x, const void* residual, void* y, float* stats, const float* partial, int nslab,
+                                       float* workspace, void* mx_q, void* mx_s,
+                                       int B, int64_t HW, int C, float eps, int act, float slope, int dtype, void* stream) {
+    UIG_CHECK_ARG(x && y && stats && mx_q && mx_s && (partial || workspace), "uig_instnorm_act_fwd_mx: null pointer");
+    UIG_CHECK_ARG(dtype == UIG_BF16 && C % 32 == 0, "uig_instnorm_act_fwd_mx: bf16 and C %% 32 == 0 only (C=%d)", C);
+    UIG_CHECK_ARG(act == UIG_ACT_NONE || act == UIG_ACT_RELU || act == UIG_ACT_LRELU, "uig_instnorm_act_fwd_mx: bad act %d", act);
+    int CC; if (int r = check_in_args("uig_instnorm_act_fwd_mx", B, HW, C, dtype, &CC)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    int ns = nslab;
+    if (partial == nullptr) {
+        ns = stats_slabs(HW, CC);
+        hipLaunchKernelGGL((in_stats_kernel<bf16_t, 0>), dim3(ns, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, workspace, (long)HW, C, CC, ns, 0, 0.f);
+        UIG_LAUNCH_CHECK("uig_instnorm_act_fwd_mx(stats)");
+        partial = workspace;
+    }
+    const int na = apply_slabs(HW, CC);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 15) / 16), dim3(256), 0, s, partial, stats, B * C, C, ns, 1.0 / (double)HW, eps, 0, 0, 0);
+    UIG_LAUNCH_CHECK("uig_instnorm_act_fwd_mx(finalize)");
+    hipLaunchKernelGGL((in_apply_fwd_kernel<bf16_t>), dim3(na, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, stats, (long)HW, C, CC, na, act, slope,
+                       (unsigned char*)mx_q, (unsigned char*)mx_s);
+    UIG_LAUNCH_CHECK("uig_instnorm_act_fwd_mx(apply)");
+    return 0;
+}
+
+extern "C" int uig_instnorm_act_bwd_colsum_mx(const void* dy, const void* x, const float* stats, void* dx, float* workspace,
+                                              float* colsum_partial, void* mx_q, void* mx_s, int B, int64_t HW, int C, int act, float slope,
+                                              int dtype, void* stream) {
+    UIG_CHECK_ARG(colsum_partial && mx_q && mx_s, "uig_instnorm_act_bwd_colsum_mx: null pointer");
+    UIG_CHECK_ARG(dtype == UIG_BF16 && C % 32 == 0, "uig_instnorm_act_bwd_colsum_mx: bf16 and C %% 32 == 0 only (C=%d)", C);
+    return instnorm_bwd_impl(dy, x, stats, dx, workspace, colsum_partial, B, HW, C, act, slope, dtype, stream, (unsigned char*)mx_q, (unsigned char*)mx_s);
 }

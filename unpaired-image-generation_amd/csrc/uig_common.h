@@ -159,6 +159,34 @@ __device__ __forceinline__ void store_tile_via_lds(const f32x4_t (&acc)[NT][MT],
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// MX block-scaled fp8 quantisation of 8 consecutive channels held by this lane; the 4 lanes that hold one 32-channel block are
+// adjacent (lane & 3 = position in the block) and must all be active.  Returns the 8 e4m3 bytes; sbyte = the block's E8M0
+// scale byte: 2^(floor(log2(amax)) - 8) (e4m3 emax = 8), 127 (x1) for an all-zero block.  Elements = RNE(x / scale) clamped to
+// +-448 first (v_cvt_pk_fp8_f32 returns NaN above 464).  One definition for the stand-alone quantiser and the fused epilogues.
+__device__ __forceinline__ u32x2_t mx_quantize8(const float* f, int& sbyte) {
+    float am = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(f[e]));
+    am = fmaxf(am, __shfl_xor(am, 1, 64));
+    am = fmaxf(am, __shfl_xor(am, 2, 64));
+    const int eb = (int)((__float_as_uint(am) >> 23) & 0xff);                  // biased exponent of amax (0 for zero / subnormal)
+    const int sb = am == 0.f ? 127 : min(max(eb - 8, 0), 254);
+    const float inv = __uint_as_float((unsigned)(254 - sb) << 23);              // 2^(127 - sb), exact (sb <= 246 for finite input)
+    unsigned w[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(f[4 * h + e] * inv, -448.f), 448.f);
+        int p = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+        p = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], p, true);
+        w[h] = (unsigned)p;
+    }
+    sbyte = sb;
+    return u32x2_t{w[0], w[1]};
+}
+
 // host-side error plumbing (defined in uig_capi.hip)
 int uig_set_error(int code, const char* fmt, ...);
 void uig_note_conv_kernel(int id);      // UIG_K_* of include/uig.h, read back by uig_debug_last_conv_kernel()

@@ -38,6 +38,8 @@ SIGNATURES = {
     "uig_conv3x3_mx_fp8_applicable": (_i, [_i] * 5),
     "uig_conv3x3_mx_fp8": (_i, [_vp] * 8 + [_i] + [_vp] * 4 + [_i] * 8 + [_i, _f, _vp]),
     "uig_mx_quantize": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "uig_instnorm_act_fwd_mx": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _f, _i, _f, _i, _vp]),
+    "uig_instnorm_act_bwd_colsum_mx": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _vp]),
     "uig_wgrad_workspace_bytes": (_sz, [_i] * 5),
     "uig_wgrad_tile_rows": (_i, [_i, _i, _i]),
     "uig_debug_set_wgrad_wide": (None, [_i]),
@@ -95,7 +97,7 @@ def lib() -> C.CDLL:
         # A/B switches without rebuilding: UIG_DEBUG_HOOKS="gemv=0,wgrad_rows=0" calls uig_debug_set_<name>(value)
         for item in filter(None, os.environ.get("UIG_DEBUG_HOOKS", "").split(",")):
             name, _, val = item.partition("=")
-            getattr(l, "uig_debug_set_" + name.strip())(int(val))
+            getattr(l, "uig_debug_set_" + name.strip())(*[int(v) for v in val.split(":")])      # "strip_pk=2:0": two-argument hook
         _lib = l
     return _lib
 

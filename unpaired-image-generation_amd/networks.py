@@ -98,11 +98,12 @@ class InstNormAct(nn.Module):
     def __init__(self, act=L.ACT_NONE, slope=0.0, eps=1e-5):
         super().__init__()
         self.act, self.slope, self.eps = act, slope, eps
+        self.mx_fwd = self.mx_bwd = False      # fp8 generators: also emit the MX fp8 form of the output / of the backward's dx
 
     def forward(self, x, residual=None, skip_link=None):
-        if ops.INFER_FUSED_IN and not torch.is_grad_enabled() and ops.instnorm_infer_applicable(x):      # inference: no statistics kept, finalize fused into the apply launch
+        if ops.INFER_FUSED_IN and not torch.is_grad_enabled() and not self.mx_fwd and ops.instnorm_infer_applicable(x):      # inference: no statistics kept, finalize fused into the apply launch
             return ops.instnorm_infer(x, residual, self.act, self.slope, self.eps)
-        return ops.InstNormActFn.apply(x, residual, self.act, self.slope, self.eps, skip_link)
+        return ops.InstNormActFn.apply(x, residual, self.act, self.slope, self.eps, skip_link, self.mx_fwd, self.mx_bwd)
 
 
 class ResBlock(nn.Module):
@@ -211,9 +212,18 @@ class Generator(_PhysNet):
         self.in_ch, self.out_ch, self.compute_dtype = in_ch, out_ch, dtype
         self._mark_in_producers()
         if fp8:
-            for m in self:
+            mods = list(self)
+            for i, m in enumerate(mods):
                 if isinstance(m, ResBlock):
                     m.b[1].enable_fp8(); m.b[5].enable_fp8()
+                    # quantisation fused into the InstanceNorm launches on either side of the fp8 convolutions (ops.FUSE_MX_QUANT):
+                    # forward: the norm whose output a ResBlock conv reads; backward: the norm whose dx is a ResBlock conv's dy
+                    m.b[2].mx_fwd = m.b[2].mx_bwd = m.b[6].mx_bwd = ops.FUSE_MX_QUANT
+                    m.b[6].mx_fwd = ops.FUSE_MX_QUANT and i + 1 < len(mods) and isinstance(mods[i + 1], ResBlock)
+                    if not isinstance(mods[i - 1], ResBlock):      # the norm (+ slot) in front of the first ResBlock
+                        prev = [k for k in mods[:i] if isinstance(k, InstNormAct)]
+                        if prev:
+                            prev[-1].mx_fwd = ops.FUSE_MX_QUANT
 
 
 class Discriminator(_PhysNet):

@@ -20,6 +20,7 @@ REFLECT_DGRAD_DIRECT = os.environ.get("UIG_REFLECT_DGRAD_DIRECT", "1") != "0"   
 PAIR_WGRAD = os.environ.get("UIG_PAIR_WGRAD", "1") != "0"                   # paired layers: both networks' weight-gradient partials in one launch where the library supports it
 FUSE_SKIP_GRAD = os.environ.get("UIG_FUSE_SKIP_GRAD", "1") != "0"           # ResBlock: the skip path's gradient is added in conv1's input-gradient epilogue instead of by a separate add kernel
 PARALLEL_BACKWARD = os.environ.get("UIG_PARALLEL_BACKWARD", "1") != "0"      # run a conv's parameter-gradient kernels concurrently with its input-gradient kernel
+FUSE_MX_QUANT = os.environ.get("UIG_FUSE_MX_QUANT", "1") != "0"            # fp8 path: MX quantisation of activations / gradients inside the InstanceNorm launches
 _SIDE_STREAMS = {}
 _DEFER_JOIN = {}
 
@@ -244,6 +245,15 @@ def mx_quantize(t: torch.Tensor):
     return q, s
 
 
+def _mx_operand(t: torch.Tensor):
+    """(q, s) of an activation / gradient tensor: the pair its producing InstanceNorm launch attached (`_uig_mx`, fused
+    quantisation), else a stand-alone quantiser pass"""
+    pre = getattr(t, "_uig_mx", None)
+    if pre is not None and pre[0].shape == t.shape:
+        return pre
+    return mx_quantize(t)
+
+
 def mx_applicable(spec: ConvSpec, B: int, H: int, W: int) -> bool:
     """can this layer's forward / input gradient run on the MX fp8 kernel? (3x3 stride-1 pad-1 conv, 128-multiples of channels)"""
     return (spec.kind == "conv" and spec.k == 3 and spec.stride == 1 and spec.pad == 1 and spec.act == L.ACT_NONE
@@ -293,7 +303,7 @@ def conv_forward(spec: ConvSpec, x: torch.Tensor, wp_fwd: torch.Tensor, bias: to
         nslab = Ho * Wo // 64
         part = torch.empty((B * nslab * spec.cout_store * 2,), device=x.device, dtype=torch.float32)
     if mx is not None:
-        xq, xs = mx_quantize(x)
+        xq, xs = _mx_operand(x)
         _conv3x3_mx(xq, xs, mx, bias, pair[1] if pair is not None else None, pair[2] if pair is not None else 0, y, spec.cout, pm, mode,
                     spec.act, spec.slope, part)
     else:
@@ -344,7 +354,7 @@ def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, 
                                                 _dt(dy), s), "uig_reflect3x3_dgrad_border")
         dx = torch.empty((B, H, W, spec.cin_p), device=dy.device, dtype=dy.dtype)
         if mx is not None:       # main term on the MX fp8 kernel (dy quantised here); the mirrored-border GEMM above stays bf16
-            dq, ds = mx_quantize(dy)
+            dq, ds = _mx_operand(dy)
             _conv3x3_mx(dq, ds, mx, None, None, pair[2] if pair is not None else 0, dx, spec.cin, L.PAD_ZERO, L.GATHER_TRANSPOSED,
                         L.ACT_NONE, 0.0, None, bord, res_add)
         else:
@@ -519,6 +529,7 @@ def _conv_backward(ctx, dy, layers, group):
     spec = layers[0].spec
     x, y = ctx.saved_tensors
     colsum = getattr(dy, "_uig_colsum", None) if dy.is_contiguous() else None
+    dy_mx = getattr(dy, "_uig_mx", None) if dy.is_contiguous() else None
     dy = dy.contiguous()
     if spec.act != L.ACT_NONE:
         colsum = None      # epilogue activation backward on the saved output
@@ -526,6 +537,8 @@ def _conv_backward(ctx, dy, layers, group):
         L.check(L.lib().uig_act_bwd(_p(dy), _p(y), _p(g), dy.numel(), spec.act, spec.slope, _dt(dy), _stream()), "uig_act_bwd")
         dy = g
     dy = _dy_padded(spec, dy)
+    if dy_mx is not None and spec.act == L.ACT_NONE and dy_mx[0].shape == dy.shape and getattr(dy, "_uig_mx", None) is None:
+        dy._uig_mx = dy_mx
     npar = len(layers)
     need_x = ctx.needs_input_grad[0]
     need_w = [ctx.needs_input_grad[1 + 2 * i] for i in range(npar)]
@@ -650,7 +663,9 @@ def instnorm_infer_applicable(x) -> bool:
 
 class InstNormActFn(Function):
     @staticmethod
-    def forward(ctx, x, residual, act, slope, eps, skip_link=None):
+    def forward(ctx, x, residual, act, slope, eps, skip_link=None, mx_fwd=False, mx_bwd=False):
+        """mx_fwd / mx_bwd: also emit the MX fp8 form of the output / of the backward's dx (attribute `_uig_mx` of that tensor) for
+        the fp8 convolution that consumes it (BASELINE configs[4])"""
         _chk_phys(x, "instnorm")
         B, H, W, C = x.shape
         lib = L.lib()
@@ -658,7 +673,15 @@ class InstNormActFn(Function):
         stats = torch.empty((B, C, 2), device=x.device, dtype=torch.float32)
         y = torch.empty_like(x)
         pre = getattr(x, "_uig_in_partial", None)
-        if pre is not None and pre[0].numel() == B * pre[1] * C * 2:      # statistics already accumulated by the conv epilogue
+        ctx.mx_bwd = bool(mx_bwd) and x.dtype == torch.bfloat16 and C % 32 == 0
+        if mx_fwd and x.dtype == torch.bfloat16 and C % 32 == 0:
+            q = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+            s = torch.empty((B, H, W, C // 32), device=x.device, dtype=torch.uint8)
+            have = pre is not None and pre[0].numel() == B * pre[1] * C * 2
+            L.check(lib.uig_instnorm_act_fwd_mx(_p(x), _p(residual), _p(y), _p(stats), _p(pre[0]) if have else None, pre[1] if have else 0,
+                                                _p(ws), _p(q), _p(s), B, H * W, C, eps, act, slope, _dt(x), _stream()), "uig_instnorm_act_fwd_mx")
+            y._uig_mx = (q, s)
+        elif pre is not None and pre[0].numel() == B * pre[1] * C * 2:      # statistics already accumulated by the conv epilogue
             L.check(lib.uig_instnorm_act_fwd_pre(_p(x), _p(residual), _p(y), _p(stats), _p(pre[0]), pre[1], B, H * W, C, eps, act,
                                                  slope, _dt(x), _stream()), "uig_instnorm_act_fwd_pre")
         else:
@@ -672,14 +695,14 @@ class InstNormActFn(Function):
     def backward(ctx, dy):
         x, stats = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = instnorm_backward(dy, x, stats, ctx.act, ctx.slope)
+        dx = instnorm_backward(dy, x, stats, ctx.act, ctx.slope, ctx.mx_bwd)
         dres = dy if ctx.has_res else None
         if dres is not None and ctx.skip_link is not None and ctx.needs_input_grad[1]:
             ctx.skip_link.grad, dres = dres, None       # handed to the block's first conv (SkipLink), not to autograd
-        return dx, dres, None, None, None, None
+        return dx, dres, None, None, None, None, None, None
 
 
-def instnorm_backward(dy, x, stats, act, slope):
+def instnorm_backward(dy, x, stats, act, slope, emit_mx=False):
     """dx of InstanceNorm(+activation).  dx is also the gradient of the convolution output in front of the norm: its
     per-channel column sums are that conv's bias gradient.  The apply kernel emits them as per-block partials (no second
     pass over dx); the conv backward picks them up through the attribute `_uig_colsum` (same tensor object: the conv
@@ -690,8 +713,15 @@ def instnorm_backward(dy, x, stats, act, slope):
     dx = torch.empty_like(x)
     slabs = int(lib.uig_instnorm_bwd_colsum_slabs(B, H * W, C, _dt(x)))
     cpart = torch.empty((slabs * C * 2,), device=x.device, dtype=torch.float32)
-    L.check(lib.uig_instnorm_act_bwd_colsum(_p(dy), _p(x), _p(stats), _p(dx), _p(ws), _p(cpart), B, H * W, C, act, slope,
-                                            _dt(x), _stream()), "uig_instnorm_act_bwd_colsum")
+    if emit_mx:      # dx is the dy of an fp8 convolution: its MX form comes out of the same launch
+        q = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+        s = torch.empty((B, H, W, C // 32), device=x.device, dtype=torch.uint8)
+        L.check(lib.uig_instnorm_act_bwd_colsum_mx(_p(dy), _p(x), _p(stats), _p(dx), _p(ws), _p(cpart), _p(q), _p(s), B, H * W, C, act, slope,
+                                                   _dt(x), _stream()), "uig_instnorm_act_bwd_colsum_mx")
+        dx._uig_mx = (q, s)
+    else:
+        L.check(lib.uig_instnorm_act_bwd_colsum(_p(dy), _p(x), _p(stats), _p(dx), _p(ws), _p(cpart), B, H * W, C, act, slope,
+                                                _dt(x), _stream()), "uig_instnorm_act_bwd_colsum")
     dx._uig_colsum = (cpart, slabs // B, C)
     return dx
 
