@@ -66,6 +66,15 @@ int uig_conv_gather(const void* x, const void* wp, const float* bias, void* y,
                     int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
                     int act, float slope, int dtype, void* stream);
 
+/* Convenience boundary of SURVEY.md §8(b) (contiguous NCHW activations, OIHW fp32 weight, any repack internal and counted in
+ * the call): aten::convolution for Conv2d (groups 1, dilation 1), pad_mode zero or reflect.  Three extra passes (NCHW ->
+ * NHWC, weight pack, NHWC -> NCHW) run inside; the hot path avoids them by keeping NHWC between layers.
+ *   x (B,Cin,H,W) dtype; w (Cout,Cin,kH,kW) fp32; bias fp32[Cout] or NULL; y (B,Cout,Ho,Wo) dtype; workspace: ..._workspace_bytes */
+size_t uig_conv2d_fwd_workspace_bytes(int B, int Cin, int H, int W, int Cout, int kH, int kW, int stride, int pad, int dtype);
+int uig_conv2d_fwd(const void* x, const float* w, const float* bias, void* y,
+                   int B, int Cin, int H, int W, int Cout, int kH, int kW, int stride, int pad, int pad_mode, int dtype,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
 /* Paired launch: the same convolution for TWO networks of identical architecture in one grid (CycleGAN's G_A/G_B and
  * D_A/D_B always process same-shaped batches).  Images b < group_images use (wp, bias), the others (wp2, bias2). */
 int uig_conv_gather_pair(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2,

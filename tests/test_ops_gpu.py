@@ -659,3 +659,31 @@ def test_strip_persistent_equals_tile_per_block_fp32():
         xin = F.pad(x, (1, 1, 1, 1), mode="reflect")
         yref = torch.cat([F.conv2d(xin[:12], l1.weight.cpu(), l1.bias.cpu()), F.conv2d(xin[12:], l2.weight.cpu(), l2.bias.cpu())])
     assert (ops.from_nhwc(a, 128).cpu() - yref).abs().max() <= _tol(torch.float32, yref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 19, 30, 26, 37, 3, 1, 1, "reflect"), (1, 3, 64, 64, 64, 7, 1, 3, "reflect"), (2, 64, 33, 40, 128, 3, 2, 1, "zero")],
+                         ids=["c19-37k3", "c3-64k7", "c64-128k3s2"])
+def test_conv2d_fwd_nchw_boundary(case, dtype):
+    """SURVEY §8(b)'s contiguous-NCHW boundary as ONE C call (uig_conv2d_fwd: repacks inside): aten::convolution on NCHW tensors,
+    channel counts that are not multiples of 8 included, against F.conv2d."""
+    u, ops, networks = _mods()
+    lib = u.lib.lib()
+    B, cin, H, W, cout, k, s, p, pm = case
+    torch.manual_seed(zlib.crc32(repr(case).encode()) % 100000)
+    x = torch.rand(B, cin, H, W) * 2 - 1
+    w = torch.randn(cout, cin, k, k) * 0.05
+    b = torch.randn(cout) * 0.1
+    rnd = _bf if dtype == torch.bfloat16 else (lambda t: t)
+    xin = F.pad(rnd(x), (p, p, p, p), mode="reflect") if pm == "reflect" else rnd(x)
+    yref = F.conv2d(xin, rnd(w), b, s, 0 if pm == "reflect" else p)
+    xd, wd, bd = x.to(dtype).cuda().contiguous(), w.cuda().contiguous(), b.cuda()
+    y = torch.empty(yref.shape, device="cuda", dtype=dtype)
+    dt = u.lib.BF16 if dtype == torch.bfloat16 else u.lib.F32
+    n = int(lib.uig_conv2d_fwd_workspace_bytes(B, cin, H, W, cout, k, k, s, p, dt))
+    ws = torch.empty(n, device="cuda", dtype=torch.uint8)
+    rc = lib.uig_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, cin, H, W, cout, k, k, s, p,
+                            u.lib.PAD_REFLECT if pm == "reflect" else u.lib.PAD_ZERO, dt, ws.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    u.lib.check(rc, "uig_conv2d_fwd")
+    assert (y.float().cpu() - yref).abs().max() <= _tol(dtype, yref)
+    assert lib.uig_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, cin, H, W, cout, k, k, s, p, 0, dt, ws.data_ptr(), 16, None) < 0
