@@ -96,6 +96,19 @@ int uig_conv_gather_ex(const void* x, const void* wp, const float* bias, const v
                        int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
                        int act, float slope, int dtype, void* stream);
 
+/* uig_conv_gather_ex that ALSO emits the statistics of the InstanceNorm BACKWARD which consumes this launch's output as its dy
+ * (the output of a ResBlock conv's input-gradient launch is the dy of the norm in front of that conv): bst_x = that norm's
+ * saved input (shape and dtype of y), bst_stats = its (mean, rstd) fp32[B][ldc][2], bst_act / bst_slope = its activation;
+ * bst_partial fp32[B][Ho*Wo/64][Nstore][2] receives (sum g, sum g*xhat) per 64-pixel slab, g = dy * act'(xhat), computed on
+ * the values as stored - exactly what the norm's own statistics pass would read back.  uig_instnorm_act_bwd_colsum_pre then
+ * skips that pass (one full read of dy and x).  bf16 strip-kernel launches with border_add and / or res_add, Ho*Wo % 64 == 0. */
+int uig_conv_gather_bst(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2,
+                        int group_images, float* in_partial, const void* border_add, const void* res_add, void* y,
+                        int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
+                        int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
+                        int act, float slope, int dtype,
+                        const void* bst_x, const float* bst_stats, int bst_act, float bst_slope, float* bst_partial, void* stream);
+
 /* Input gradient of a reflection-padded (pad 1) 3x3 stride-1 conv WITHOUT the padded (H+2)x(W+2) gradient + fold:
  * this computes the mirrored-border terms (8 groups: top/bottom/left/right lines + 4 corners) into bord[B][8][H][ldc];
  * then uig_conv_gather_ex(dy, ..., transposed, pad=1, zero, border_add=bord) produces dx on the exact HxW grid. */
@@ -115,7 +128,9 @@ int uig_conv3x3_mx_fp8(const void* xq, const void* xs, const void* wq, const voi
                        const void* wq2, const void* ws2, const float* bias2, int group_images,
                        float* in_partial, const void* border_add, const void* res_add, void* y,
                        int B, int H, int W, int Cin, int Nrows, int pad_mode, int gather_mode, int ldc,
-                       int act, float slope, void* stream);
+                       int act, float slope,
+                       const void* bst_x, const float* bst_stats, int bst_act, float bst_slope, float* bst_partial /* all NULL / 0: off; see uig_conv_gather_bst */,
+                       void* stream);
 /* InstanceNorm forward / backward that ALSO emit the MX fp8 form (mx_q [B*HW][C] e4m3, mx_s [B*HW][C/32] E8M0) of exactly the
  * bf16 tensor they write - the operand of the fp8 convolution that consumes it, without the stand-alone quantiser's extra pass.
  * fwd: partial != NULL as uig_instnorm_act_fwd_pre, else as uig_instnorm_act_fwd (workspace).  bf16, C a multiple of 32. */
@@ -219,6 +234,11 @@ int uig_instnorm_act_bwd(const void* dy, const void* x, const float* stats, void
  * (fp32[uig_instnorm_bwd_colsum_slabs(B,HW,C,dtype) * C * 2]): the bias gradient of the convolution in front of this
  * InstanceNorm is then uig_bias_grad_from_partials(colsum_partial, db, slabs, ...) with no second pass over dx. */
 int uig_instnorm_bwd_colsum_slabs(int B, int64_t HW, int C, int dtype);
+/* the same with the backward statistics already produced by the launch that wrote dy (uig_conv_gather_bst / uig_conv3x3_mx_fp8:
+ * partial fp32[B][nslab][C][2], nslab = HW/64): no statistics pass.  mx_q / mx_s optional (NULL, or as uig_instnorm_act_bwd_colsum_mx). */
+int uig_instnorm_act_bwd_colsum_pre(const void* dy, const void* x, const float* stats, void* dx, float* workspace,
+                                    float* colsum_partial, const float* partial, int nslab, void* mx_q, void* mx_s,
+                                    int B, int64_t HW, int C, int act, float slope, int dtype, void* stream);
 int uig_instnorm_act_bwd_colsum(const void* dy, const void* x, const float* stats, void* dx, float* workspace,
                                 float* colsum_partial, int B, int64_t HW, int C, int act, float slope, int dtype, void* stream);
 int uig_bias_grad_from_partials(const float* colsum_partial, float* db, int nslab_total, int C, int Nreal,

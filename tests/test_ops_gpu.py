@@ -687,3 +687,63 @@ def test_conv2d_fwd_nchw_boundary(case, dtype):
     u.lib.check(rc, "uig_conv2d_fwd")
     assert (y.float().cpu() - yref).abs().max() <= _tol(dtype, yref)
     assert lib.uig_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, cin, H, W, cout, k, k, s, p, 0, dt, ws.data_ptr(), 16, None) < 0
+
+
+@pytest.mark.parametrize("B,group,act", [(16, 8, "relu"), (8, 0, "none"), (3, 0, "relu")], ids=["paired16-relu", "single8-none", "small3-relu"])
+def test_instnorm_backward_statistics_from_dgrad_epilogue(B, group, act):
+    """InstanceNorm -> 3x3 reflect conv (the ResBlock pattern): the norm's backward statistics (sum g, sum g*xhat) come out of the
+    epilogue of the conv's input-gradient launch (which writes the norm's dy) instead of the norm's own pass over dy and x.
+    Against (a) the same chain with that fusion off: the conv's dx bitwise equal, the norm's dx within bf16 rounding (only the
+    fp32 summation order of the statistics differs); (b) the oracle (F.instance_norm + F.conv2d autograd), bf16 tolerance."""
+    u, ops, networks = _mods()
+    dt = torch.bfloat16
+    torch.manual_seed(300 + B)
+    g = group if group else B
+    ls = [networks.ConvLayer("conv", 256, 256, 3, 1, 1, "reflect", dtype=dt, device="cuda") for _ in range(2 if group else 1)]
+    for l in ls:
+        l.ensure_packed()
+    A = u.lib.ACT_RELU if act == "relu" else u.lib.ACT_NONE
+    x = torch.randn(B, 256, 64, 64) * 1.5 + 0.3
+    dy = torch.randn(B, 256, 64, 64) * 0.5
+    res = torch.randn(B, 256, 64, 64) * 0.5
+
+    def run(fuse):
+        old = ops.FUSE_BWD_STATS
+        ops.FUSE_BWD_STATS = fuse
+        try:
+            for l in ls:
+                l.weight.grad = None; l.bias.grad = None
+            xp = ops.to_nhwc(x.cuda(), dt).requires_grad_(True)
+            h = ops.InstNormActFn.apply(xp * 1.0, None, A, 0.0, 1e-5)
+            assert (getattr(h, "_uig_bst", None) is not None) == fuse
+            link = ops.SkipLink()
+            if group:
+                y = ops.PairConvFn.apply(h, ls[0].weight, ls[0].bias, ls[1].weight, ls[1].bias, ls[0], ls[1], g, link)
+            else:
+                y = ops.ConvFn.apply(h, ls[0].weight, ls[0].bias, ls[0], link)
+            link.grad = ops.to_nhwc(res.cuda(), dt)
+            hg = []
+            h.register_hook(lambda t: hg.append(t.clone()))
+            y.backward(ops.to_nhwc(dy.cuda(), dt))
+            return xp.grad.clone(), hg[0]
+        finally:
+            ops.FUSE_BWD_STATS = old
+
+    dx1, dh1 = run(True)
+    dx0, dh0 = run(False)
+    assert torch.equal(dh1, dh0), "the conv's input gradient must not change"
+    sc = float(dx0.float().abs().max())
+    assert float((dx1.float() - dx0.float()).abs().max()) <= 1e-2 * sc
+    assert float((dx1.float() - dx0.float()).abs().mean()) <= 2e-4 * sc          # the same numbers up to a few roundings at bf16 ties
+    # oracle
+    xr = _bf(x).requires_grad_(True)
+    hr = F.instance_norm(xr, eps=1e-5)
+    hr = F.relu(hr) if act == "relu" else hr
+    hb = _bf(hr.detach()).requires_grad_(True)                                   # the conv sees the bf16-rounded norm output
+    parts = [(0, g, 0)] + ([(g, B, 1)] if group else [])
+    yr = torch.cat([F.conv2d(F.pad(hb[a:e], (1, 1, 1, 1), mode="reflect"), _bf(ls[i].weight.detach().cpu()), ls[i].bias.detach().cpu()) for a, e, i in parts])
+    yr.backward(_bf(dy))
+    hr.backward(_bf(hb.grad + _bf(res)))
+    ref = xr.grad
+    got = ops.from_nhwc(dx1, 256).cpu()
+    assert (got - ref).abs().max() <= 2.5e-2 * float(ref.abs().max()), float((got - ref).abs().max()) / float(ref.abs().max())

@@ -16,6 +16,8 @@
 #include "uig_common.h"
 #include <algorithm>
 
+struct UigBst { const void* x; const float* stats; float* partial; int act; float slope; };     // as in conv_strip_desc.h
+
 struct GatherDesc {
     int B, H, W, Cin;
     int Mh, Mw;            // per-phase iteration grid (per image)
@@ -383,7 +385,7 @@ static int dispatch_igemm(const void* x, const void* wp, const float* bias, void
 int uig_try_conv_strip(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
                        float* in_partial, const void* border_add, const void* res_add, void* y, int B, int H, int W, int Cin, int Nrows,
                        int k, int pad_mode, const int* taps, int ntaps, int dh_min, int dh_max, int Ho, int Wo, int ldc, int Nstore,
-                       int act, float slope, int dtype, long x_bytes, long w_bytes, hipStream_t s, int* rc_out);
+                       int act, float slope, int dtype, long x_bytes, long w_bytes, hipStream_t s, int* rc_out, const UigBst* bst);
 
 int uig_try_conv_cin8(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
                       void* y, int B, int H, int W, int Cin, int Nrows, int pad_mode, const int* taps, int ntaps,
@@ -406,7 +408,7 @@ static int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b
 static int conv_gather_impl(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
                             float* in_partial, const void* border_add, const void* res_add, void* y, int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
                             int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
-                            int act, float slope, int dtype, void* stream) {
+                            int act, float slope, int dtype, void* stream, const UigBst* bst = nullptr) {
     UIG_CHECK_ARG(x && wp && y, "uig_conv_gather: null pointer");
     if (wp2 != nullptr) UIG_CHECK_ARG(group_images > 0 && group_images < B, "uig_conv_gather_pair: group_images=%d must be in (0, B=%d)", group_images, B);
     UIG_CHECK_ARG(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "uig_conv_gather: bad shape B=%d H=%d W=%d Ho=%d Wo=%d", B, H, W, Ho, Wo);
@@ -500,9 +502,10 @@ static int conv_gather_impl(const void* x, const void* wp, const float* bias, co
         int dmin = 127, dmax = -127, rc = 0;
         for (int t = 0; t < kH * kW; ++t) { const int dh = (d.tap[t] & 255) - 128; dmin = std::min(dmin, dh); dmax = std::max(dmax, dh); }
         if (uig_try_conv_strip(x, wp, bias, wp2, bias2, group_images, in_partial, border_add, res_add, y, B, H, W, Cin, Nrows, kH, pad_mode, d.tap, kH * kW, dmin, dmax,
-                               Ho, Wo, ldc, Nstore, act, slope, dtype, (long)d.x_bytes, (long)d.w_bytes, s, &rc))
+                               Ho, Wo, ldc, Nstore, act, slope, dtype, (long)d.x_bytes, (long)d.w_bytes, s, &rc, bst))
             return rc;
     }
+    UIG_CHECK_ARG(bst == nullptr, "uig_conv_gather_bst: the fused InstanceNorm-backward statistics need the bf16 strip kernel with border / residual terms");
     UIG_CHECK_ARG(border_add == nullptr && res_add == nullptr, "uig_conv_gather_ex: border_add / res_add need the stride-1 3x3 strip kernel (query uig_conv_strip_applicable)");
     if (wp2 != nullptr) {
         const long grows = (long)group_images * d.Mh * d.Mw;
@@ -549,6 +552,20 @@ extern "C" int uig_conv_gather_ex(const void* x, const void* wp, const float* bi
                             pad_mode, gather_mode, Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
 }
 
+
+// uig_conv_gather_ex plus the statistics of the InstanceNorm BACKWARD that consumes this launch's output as its dy (see
+// StripDesc::bst_*): bf16 strip-kernel launches with border_add and / or res_add only (3x3 stride-1 input gradients).
+extern "C" int uig_conv_gather_bst(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2,
+                                   int group_images, float* in_partial, const void* border_add, const void* res_add, void* y,
+                                   int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
+                                   int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
+                                   int act, float slope, int dtype,
+                                   const void* bst_x, const float* bst_stats, int bst_act, float bst_slope, float* bst_partial, void* stream) {
+    UIG_CHECK_ARG(bst_x && bst_stats && bst_partial, "uig_conv_gather_bst: null statistics pointer");
+    const UigBst b{bst_x, bst_stats, bst_partial, bst_act, bst_slope};
+    return conv_gather_impl(x, wp, bias, wp2, bias2, wp2 ? group_images : 0, in_partial, border_add, res_add, y, B, H, W, Cin, Nrows, kH, kW, stride, pad,
+                            pad_mode, gather_mode, Ho, Wo, ldc, Nstore, act, slope, dtype, stream, &b);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Border terms of the input gradient of a reflection-padded (pad 1) 3x3 stride-1 convolution.

@@ -19,7 +19,17 @@ struct StripDesc {
     const void* border_add;  // optional: bord[B][8][S][ldc] of uig_reflect3x3_dgrad_border, added to rows 1 / H-2 and cols 1 / W-2
     unsigned long long* dbg; // diagnostic build only (STAMP): per-wave cycle sums {wait+barrier, DMA issue, reads+MFMA, total}
     int wo_magic;            // persistent kernel: ceil(2^20 / Wo), set by uig_launch_strip_pk
+    // optional: statistics of the InstanceNorm BACKWARD that consumes this launch's output as its dy (input-gradient launches):
+    // bst_x = that norm's saved input (shape of y), bst_stats = its (mean, rstd) [B][ldc][2], bst_act / bst_slope its activation;
+    // bst_partial [B][HoWo/64][Nstore][2] receives (sum g, sum g * xhat), g = dy * act'(xhat), per 64-pixel slab - what the
+    // norm's own statistics pass (one read of dy and x) would have produced (uig_instnorm_act_bwd_colsum_pre consumes it)
+    const void* bst_x;
+    const float* bst_stats;
+    float* bst_partial;
+    int bst_act; float bst_slope;
 };
+
+struct UigBst { const void* x; const float* stats; float* partial; int act; float slope; };
 
 template <typename T> struct MmaS;
 template <> struct MmaS<bf16_t> {
@@ -89,31 +99,57 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
                 const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<void*>(hasr ? d.res_add : d.border_add), 0, hasr ? (unsigned)((long)d.B * HoWo * d.ldc * (int)sizeof(T)) : 0u, 0x00020000);
                 constexpr int NI = 8;                                  // 64 rows / 8 rows per store instruction
+                constexpr int ND = 2;                                  // rows in flight: a ring of ND prefetch slots, refilled as rows are stored (2 and 4 measure the same; 4 spills with the statistics path)
                 const int c = lane % 8, r0 = lane / 8;
                 auto boff = [&](int phase, int pos) -> int {
                     return (int)(((((long)img * 8 + phase) * S + pos) * d.ldc + nw0 + c * E) * (long)sizeof(T));
                 };
-                u32x4_t pre[NI][2];                                    // border term (line or column), residual tensor
+                // statistics of the InstanceNorm backward that takes this output as its dy (bst_*): the norm's saved input is
+                // prefetched like the residual; (sum g, sum g * xhat) of the lane's 8 channels over its 8 rows, combined below
+                const bool bst = d.bst_partial != nullptr && pw < HoWo;                 // wave-uniform
+                const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<void*>(bst ? d.bst_x : (hasr ? d.res_add : d.border_add)), 0, bst ? (unsigned)((long)d.B * HoWo * d.ldc * (int)sizeof(T)) : 0u, 0x00020000);
+                u32x4_t pre[ND][2], prex[ND];                          // border term (line or column), residual tensor; the norm's input
                 unsigned both = 0;                                     // bit i: row i is one of the image's four double-border pixels
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
+                auto fetch = [&](int i) {                              // row i -> slot i % ND (static after unrolling)
                     const int p = pw + r0 + 8 * i;
                     const int h = p / d.Wo, w = p - h * d.Wo;
                     const bool ok = p < HoWo;
                     const bool okb = ok & hasb;
                     const bool rt_ = okb & (h == 1), rb_ = okb & (h == S - 2), cl_ = okb & (w == 1), cr_ = okb & (w == S - 2);
                     const int o0 = (rt_ | rb_) ? boff(rt_ ? 0 : 1, w) : ((cl_ | cr_) ? boff(cl_ ? 2 : 3, h) : -1);
-                    pre[i][0] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsb, o0, 0, 0));
-                    pre[i][1] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                    pre[i % ND][0] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsb, o0, 0, 0));
+                    pre[i % ND][1] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
                         rsr, ok ? (int)((((long)img * HoWo + p) * d.ldc + nw0 + c * E) * (long)sizeof(T)) : -1, 0, 0));
                     both |= (((rt_ | rb_) & (cl_ | cr_)) ? 1u : 0u) << i;
-                }
+                };
+                auto fetch_x = [&](int i) {
+                    const int p = pw + r0 + 8 * i;
+                    prex[i % ND] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                        rsn, (bst & (p < HoWo)) ? (int)((((long)img * HoWo + p) * d.ldc + nw0 + c * E) * (long)sizeof(T)) : -1, 0, 0));
+                };
+#pragma unroll
+                for (int i = 0; i < ND; ++i) fetch(i);                 // behind the LDS transposition
+                float bmu[E], brs[E], bs1[E], bs2[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) { bmu[e] = 0.f; brs[e] = 0.f; bs1[e] = 0.f; bs2[e] = 0.f; }
+                auto mid = [&]() {                                     // the accumulators are dead here
+                    if (!bst) return;
+                    const float* sp = d.bst_stats + ((long)img * d.ldc + nw0 + c * E) * 2;
+#pragma unroll
+                    for (int e = 0; e < E; e += 2) {
+                        const f32x4_t t4 = *reinterpret_cast<const f32x4_t*>(sp + 2 * e);
+                        bmu[e] = t4[0]; brs[e] = t4[1]; bmu[e + 1] = t4[2]; brs[e + 1] = t4[3];
+                    }
+#pragma unroll
+                    for (int i = 0; i < ND; ++i) fetch_x(i);
+                };
                 auto add = [&](int r, int, const u32x4_t& v, int i) -> u32x4_t {
                     float f[E], g[E];
                     chunk_to_f32<T>(v, f);
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
-                        chunk_to_f32<T>(pre[i][k], g);
+                        chunk_to_f32<T>(pre[i % ND][k], g);
 #pragma unroll
                         for (int e = 0; e < E; ++e) f[e] += g[e];
                     }
@@ -130,9 +166,37 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
 #pragma unroll
                         for (int e = 0; e < E; ++e) f[e] += g[e];
                     }
-                    return f32_to_chunk<T>(f);
+                    const u32x4_t outc = f32_to_chunk<T>(f);
+                    if (bst) {                                         // on the values AS STORED (what the norm's own pass would read back)
+                        float gv[E], xv[E];
+                        chunk_to_f32<T>(outc, gv);
+                        chunk_to_f32<T>(prex[i % ND], xv);
+                        const bool in = pw + r < HoWo;
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            const float xh = (xv[e] - bmu[e]) * brs[e];
+                            float gg = gv[e];
+                            if (d.bst_act == UIG_ACT_RELU) gg = xh > 0.f ? gg : 0.f;
+                            else if (d.bst_act == UIG_ACT_LRELU) gg = xh > 0.f ? gg : gg * d.bst_slope;
+                            gg = in ? gg : 0.f;
+                            bs1[e] += gg; bs2[e] += gg * xh;
+                        }
+                    }
+                    if (i + ND < NI) { fetch(i + ND); if (bst) fetch_x(i + ND); }      // refill the slot just consumed
+                    return outc;
                 };
-                store_tile_via_lds<T, MT, NT>(acc, scratch, lane, nullptr, d.act, d.slope, rowp, so, min(64, HoWo - pw), add);
+                store_tile_via_lds<T, MT, NT>(acc, scratch, lane, nullptr, d.act, d.slope, rowp, so, min(64, HoWo - pw), add, mid);
+                if (bst) {                                             // combine the 8 lanes that hold the same chunk; lanes 0-7 write
+#pragma unroll
+                    for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+                        for (int e = 0; e < E; ++e) { bs1[e] += __shfl_xor(bs1[e], o, 64); bs2[e] += __shfl_xor(bs2[e], o, 64); }
+                    if (lane < 8) {
+                        float* o = d.bst_partial + (((long)img * ((HoWo + 63) / 64) + pw / 64) * d.Nstore + nw0 + lane * E) * 2;
+#pragma unroll
+                        for (int e = 0; e < E; e += 2) *reinterpret_cast<f32x4_t*>(o + 2 * e) = f32x4_t{bs1[e], bs2[e], bs1[e + 1], bs2[e + 1]};
+                    }
+                }
             } else {
             auto add = [&](int r, int c, const u32x4_t& v, int) -> u32x4_t {
                 const int p = pw + r;

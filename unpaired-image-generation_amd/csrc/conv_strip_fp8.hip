@@ -297,8 +297,11 @@ extern "C" int uig_conv3x3_mx_fp8(const void* xq, const void* xs, const void* wq
                                   const void* wq2, const void* ws2, const float* bias2, int group_images,
                                   float* in_partial, const void* border_add, const void* res_add, void* y,
                                   int B, int H, int W, int Cin, int Nrows, int pad_mode, int gather_mode, int ldc,
-                                  int act, float slope, void* stream) {
+                                  int act, float slope,
+                                  const void* bst_x, const float* bst_stats, int bst_act, float bst_slope, float* bst_partial, void* stream) {
     UIG_CHECK_ARG(xq && xs && wq && ws && y, "uig_conv3x3_mx_fp8: null pointer");
+    if (bst_partial != nullptr)
+        UIG_CHECK_ARG(bst_x && bst_stats && (border_add || res_add) && (H * W) % 64 == 0, "uig_conv3x3_mx_fp8: fused InstanceNorm-backward statistics need border_add / res_add and H*W %% 64 == 0");
     UIG_CHECK_ARG(uig_conv3x3_mx_fp8_applicable(B, H, W, Cin, Nrows) == 1,
                   "uig_conv3x3_mx_fp8: unsupported shape B=%d %dx%d Cin=%d N=%d (Cin, N multiples of 128; 256-pixel strips <= 448 rows)", B, H, W, Cin, Nrows);
     UIG_CHECK_ARG(gather_mode == UIG_GATHER_DIRECT || gather_mode == UIG_GATHER_TRANSPOSED, "uig_conv3x3_mx_fp8: bad gather_mode %d", gather_mode);
@@ -319,6 +322,7 @@ extern "C" int uig_conv3x3_mx_fp8(const void* xq, const void* xs, const void* wq
                                                          : (((1 - kh) + 128) | (((1 - kw) + 128) << 8) | (t << 16));
         }
     d.wo_magic = ((1 << 20) + W - 1) / W;
+    if (bst_partial != nullptr) { d.bst_x = bst_x; d.bst_stats = bst_stats; d.bst_partial = bst_partial; d.bst_act = bst_act; d.bst_slope = bst_slope; }
     m.xs = (const unsigned char*)xs; m.ws = (const unsigned char*)ws; m.ws2 = (const unsigned char*)ws2;
     m.xs_bytes = (unsigned)((long)B * H * W * (Cin / 32)); m.ws_bytes = (unsigned)((long)Nrows * 9 * (Cin / 32));
     constexpr int CAP = 448;

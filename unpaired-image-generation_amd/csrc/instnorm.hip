@@ -314,19 +314,23 @@ extern "C" int uig_instnorm_bwd_colsum_slabs(int B, int64_t HW, int C, int dtype
 
 static int instnorm_bwd_impl(const void* dy, const void* x, const float* stats, void* dx, float* workspace, float* colsum_partial,
                              int B, int64_t HW, int C, int act, float slope, int dtype, void* stream,
-                             unsigned char* mxq = nullptr, unsigned char* mxs = nullptr) {
+                             unsigned char* mxq = nullptr, unsigned char* mxs = nullptr, const float* pre_partial = nullptr, int pre_nslab = 0) {
     UIG_CHECK_ARG(dy && x && stats && dx && workspace, "uig_instnorm_act_bwd: null pointer");
     UIG_CHECK_ARG(act == UIG_ACT_NONE || act == UIG_ACT_RELU || act == UIG_ACT_LRELU, "uig_instnorm_act_bwd: bad act %d", act);
     int CC; if (int r = check_in_args("uig_instnorm_act_bwd", B, HW, C, dtype, &CC)) return r;
     hipStream_t s = (hipStream_t)stream;
     const int ns = stats_slabs(HW, CC), na = colsum_partial ? colsum_slabs(HW, CC) : apply_slabs(HW, CC);
     float* gm = workspace + (size_t)B * 128 * C * 2;
-    if (dtype == UIG_BF16)
-        hipLaunchKernelGGL((in_stats_kernel<bf16_t, 1>), dim3(ns, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, stats, workspace, (long)HW, C, CC, ns, act, slope);
-    else
-        hipLaunchKernelGGL((in_stats_kernel<float, 1>), dim3(ns, B), dim3(256), 0, s, (const float*)x, (const float*)dy, stats, workspace, (long)HW, C, CC, ns, act, slope);
-    UIG_LAUNCH_CHECK("uig_instnorm_act_bwd(stats)");
-    hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 15) / 16), dim3(256), 0, s, workspace, gm, B * C, C, ns, 1.0 / (double)HW, 0.f, 1, 0, 0);
+    if (pre_partial == nullptr) {
+        if (dtype == UIG_BF16)
+            hipLaunchKernelGGL((in_stats_kernel<bf16_t, 1>), dim3(ns, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, stats, workspace, (long)HW, C, CC, ns, act, slope);
+        else
+            hipLaunchKernelGGL((in_stats_kernel<float, 1>), dim3(ns, B), dim3(256), 0, s, (const float*)x, (const float*)dy, stats, workspace, (long)HW, C, CC, ns, act, slope);
+        UIG_LAUNCH_CHECK("uig_instnorm_act_bwd(stats)");
+    }
+    // (sum g, sum g*xhat) partials: this norm's own statistics pass, or the epilogue of the launch that wrote dy
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 15) / 16), dim3(256), 0, s, pre_partial ? pre_partial : workspace, gm, B * C, C,
+                       pre_partial ? pre_nslab : ns, 1.0 / (double)HW, 0.f, 1, 0, 0);
     UIG_LAUNCH_CHECK("uig_instnorm_act_bwd(finalize)");
     if (colsum_partial) {
         if (dtype == UIG_BF16)
@@ -459,4 +463,14 @@ extern "C" int uig_instnorm_act_bwd_colsum_mx(const void* dy, const void* x, con
     UIG_CHECK_ARG(colsum_partial && mx_q && mx_s, "uig_instnorm_act_bwd_colsum_mx: null pointer");
     UIG_CHECK_ARG(dtype == UIG_BF16 && C % 32 == 0, "uig_instnorm_act_bwd_colsum_mx: bf16 and C %% 32 == 0 only (C=%d)", C);
     return instnorm_bwd_impl(dy, x, stats, dx, workspace, colsum_partial, B, HW, C, act, slope, dtype, stream, (unsigned char*)mx_q, (unsigned char*)mx_s);
+}
+
+extern "C" int uig_instnorm_act_bwd_colsum_pre(const void* dy, const void* x, const float* stats, void* dx, float* workspace,
+                                               float* colsum_partial, const float* partial, int nslab, void* mx_q, void* mx_s,
+                                               int B, int64_t HW, int C, int act, float slope, int dtype, void* stream) {
+    UIG_CHECK_ARG(colsum_partial && partial && nslab > 0, "uig_instnorm_act_bwd_colsum_pre: null pointer");
+    UIG_CHECK_ARG((mx_q == nullptr) == (mx_s == nullptr), "uig_instnorm_act_bwd_colsum_pre: mx_q and mx_s go together");
+    if (mx_q != nullptr) UIG_CHECK_ARG(dtype == UIG_BF16 && C % 32 == 0, "uig_instnorm_act_bwd_colsum_pre: MX output needs bf16 and C %% 32 == 0 (C=%d)", C);
+    return instnorm_bwd_impl(dy, x, stats, dx, workspace, colsum_partial, B, HW, C, act, slope, dtype, stream,
+                             (unsigned char*)mx_q, (unsigned char*)mx_s, partial, nslab);
 }

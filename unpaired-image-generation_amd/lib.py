@@ -34,13 +34,15 @@ SIGNATURES = {
     "uig_conv_gather": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_i, _f, _i, _vp]),
     "uig_conv_gather_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp] + [_i] * 15 + [_i, _f, _i, _vp]),
     "uig_conv_gather_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp] + [_i] * 15 + [_i, _f, _i, _vp]),
+    "uig_conv_gather_bst": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp] + [_i] * 15 + [_i, _f, _i] + [_vp, _vp, _i, _f, _vp] + [_vp]),
     "uig_reflect3x3_dgrad_border": (_i, [_vp, _vp, _vp, _i, _vp] + [_i] * 7 + [_vp]),
     "uig_conv_strip_applicable": (_i, [_i] * 10),
     "uig_conv_strip_tile": (_i, [_i] * 10),
     "uig_conv3x3_mx_fp8_applicable": (_i, [_i] * 5),
-    "uig_conv3x3_mx_fp8": (_i, [_vp] * 8 + [_i] + [_vp] * 4 + [_i] * 8 + [_i, _f, _vp]),
+    "uig_conv3x3_mx_fp8": (_i, [_vp] * 8 + [_i] + [_vp] * 4 + [_i] * 8 + [_i, _f] + [_vp, _vp, _i, _f, _vp] + [_vp]),
     "uig_mx_quantize": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "uig_instnorm_act_fwd_mx": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _f, _i, _f, _i, _vp]),
+    "uig_instnorm_act_bwd_colsum_pre": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _i, _f, _i, _vp]),
     "uig_instnorm_act_bwd_colsum_mx": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _vp]),
     "uig_wgrad_workspace_bytes": (_sz, [_i] * 5),
     "uig_wgrad_tile_rows": (_i, [_i, _i, _i]),

@@ -20,6 +20,12 @@ REFLECT_DGRAD_DIRECT = os.environ.get("UIG_REFLECT_DGRAD_DIRECT", "1") != "0"   
 PAIR_WGRAD = os.environ.get("UIG_PAIR_WGRAD", "1") != "0"                   # paired layers: both networks' weight-gradient partials in one launch where the library supports it
 FUSE_SKIP_GRAD = os.environ.get("UIG_FUSE_SKIP_GRAD", "1") != "0"           # ResBlock: the skip path's gradient is added in conv1's input-gradient epilogue instead of by a separate add kernel
 PARALLEL_BACKWARD = os.environ.get("UIG_PARALLEL_BACKWARD", "1") != "0"      # run a conv's parameter-gradient kernels concurrently with its input-gradient kernel
+# InstanceNorm backward statistics (sum g, sum g*xhat) from the epilogue of the input-gradient launch that writes the norm's dy,
+# instead of the norm's own pass over dy and x.  OFF by default: measured on MI355X (scripts/bench_dgrad_nd.py, paired 16-image
+# launch) the epilogue work costs +13.7 us against the 17 us statistics kernel it removes (+9.2 vs 9 us at 8 images); whole step
+# 16.08-16.33 ms with it vs 15.98-16.00 ms without (same box).  ~700 VALU instructions per wave at 2 waves per SIMD sit on the
+# convolution's critical path, while the stand-alone pass is HBM-bound at full occupancy.  Tested opt-in (test_ops_gpu.py).
+FUSE_BWD_STATS = os.environ.get("UIG_FUSE_BWD_STATS", "0") != "0"
 FUSE_MX_QUANT = os.environ.get("UIG_FUSE_MX_QUANT", "1") != "0"            # fp8 path: MX quantisation of activations / gradients inside the InstanceNorm launches
 _SIDE_STREAMS = {}
 _DEFER_JOIN = {}
@@ -215,11 +221,16 @@ def packed_shapes(spec: ConvSpec):
 
 
 def _gather(x, wp, bias, y, B, H, W, C, nrows, spec, stride, pad, pm, mode, Ho, Wo, ldc, act, slope, what, pair=None,
-            in_partial=None, border_add=None, res_add=None):
+            in_partial=None, border_add=None, res_add=None, bst=None):
     """one uig_conv_gather launch; pair = (wp2, bias2, group_images) makes it a two-network launch; in_partial receives the
     fused InstanceNorm statistics partials; res_add (a tensor of y's shape) is added to the output in the epilogue"""
     lib = L.lib()
-    if in_partial is not None or border_add is not None or res_add is not None:
+    if bst is not None:      # (x_in, stats, act, slope, partial) of the InstanceNorm backward that consumes y as its dy
+        wp2, bias2, g = pair if pair is not None else (None, None, 0)
+        rc = lib.uig_conv_gather_bst(_p(x), _p(wp), _p(bias), _p(wp2), _p(bias2), g, _p(in_partial), _p(border_add), _p(res_add), _p(y), B, H, W, C, nrows,
+                                     spec.k, spec.k, stride, pad, pm, mode, Ho, Wo, ldc, ldc, act, slope, _dt(x),
+                                     _p(bst[0]), _p(bst[1]), bst[2], bst[3], _p(bst[4]), _stream())
+    elif in_partial is not None or border_add is not None or res_add is not None:
         wp2, bias2, g = pair if pair is not None else (None, None, 0)
         rc = lib.uig_conv_gather_ex(_p(x), _p(wp), _p(bias), _p(wp2), _p(bias2), g, _p(in_partial), _p(border_add), _p(res_add), _p(y), B, H, W, C, nrows,
                                     spec.k, spec.k, stride, pad, pm, mode, Ho, Wo, ldc, ldc, act, slope, _dt(x), _stream())
@@ -261,13 +272,15 @@ def mx_applicable(spec: ConvSpec, B: int, H: int, W: int) -> bool:
             and L.lib().uig_conv3x3_mx_fp8_applicable(B, H, W, spec.cin, spec.cout) == 1)
 
 
-def _conv3x3_mx(xq, xs, mx, bias, pair_bias, group, y, nrows, pad_mode, gather_mode, act, slope, in_partial=None, border_add=None, res_add=None):
+def _conv3x3_mx(xq, xs, mx, bias, pair_bias, group, y, nrows, pad_mode, gather_mode, act, slope, in_partial=None, border_add=None, res_add=None, bst=None):
     """one uig_conv3x3_mx_fp8 launch; mx = (wq, ws) or (wq, ws, wq2, ws2) for a paired launch"""
     B, H, W, C = xq.shape
     wq2, ws2 = (mx[2], mx[3]) if len(mx) == 4 else (None, None)
     L.check(L.lib().uig_conv3x3_mx_fp8(_p(xq), _p(xs), _p(mx[0]), _p(mx[1]), _p(bias), _p(wq2), _p(ws2), _p(pair_bias), group,
                                        _p(in_partial), _p(border_add), _p(res_add), _p(y), B, H, W, C, nrows, pad_mode, gather_mode,
-                                       y.shape[3], act, slope, _stream()), "uig_conv3x3_mx_fp8")
+                                       y.shape[3], act, slope,
+                                       _p(bst[0]) if bst else None, _p(bst[1]) if bst else None, bst[2] if bst else 0, bst[3] if bst else 0.0,
+                                       _p(bst[4]) if bst else None, _stream()), "uig_conv3x3_mx_fp8")
 
 
 def in_stats_fusable(spec: ConvSpec, H: int, W: int, B: int = 1, dtype: torch.dtype = torch.bfloat16) -> bool:
@@ -322,7 +335,10 @@ def _dy_padded(spec: ConvSpec, dy: torch.Tensor) -> torch.Tensor:
     return to_nhwc(dy.permute(0, 3, 1, 2), dy.dtype, spec.cout_p)
 
 
-def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, pair=None, res_add=None, mx=None) -> torch.Tensor:
+def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, pair=None, res_add=None, mx=None, bst=None) -> torch.Tensor:
+    """bst = (x_in, stats, act, slope) of the InstanceNorm whose backward will consume the returned dx as its dy: where the launch
+    supports it (bf16 strip / fp8 kernel with the border terms), its backward statistics come out of this launch's epilogue and
+    travel on dx as `_uig_bst_partial`."""
     """aten::convolution_backward, input gradient.  dy: (B,Ho,Wo,cout_p).  pair = (wp_dgrad2, None, group_images).
     res_add: a second gradient of the input (the ResBlock skip path's) to be summed in: fused into the launch's epilogue
     where the kernel supports it, one in-place add otherwise."""
@@ -353,13 +369,22 @@ def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, 
         L.check(lib.uig_reflect3x3_dgrad_border(_p(dy), _p(wp_dgrad), _p(wp2), g, _p(bord), B, Ho, Wo, Cd, spec.cin, spec.cin_p,
                                                 _dt(dy), s), "uig_reflect3x3_dgrad_border")
         dx = torch.empty((B, H, W, spec.cin_p), device=dy.device, dtype=dy.dtype)
+        bpart = None
+        if bst is not None and FUSE_BWD_STATS and dy.dtype == torch.bfloat16 and (H * W) % 64 == 0 and spec.cin % 64 == 0 and spec.cin_p == spec.cin \
+                and tuple(bst[0].shape) == (B, H, W, spec.cin_p) and bst[0].dtype == dy.dtype and bst[0].is_contiguous():
+            bpart = torch.empty((B * (H * W // 64) * spec.cin_p * 2,), device=dy.device, dtype=torch.float32)
+            bst = (bst[0], bst[1], bst[2], bst[3], bpart)
+        else:
+            bst = None
         if mx is not None:       # main term on the MX fp8 kernel (dy quantised here); the mirrored-border GEMM above stays bf16
             dq, ds = _mx_operand(dy)
             _conv3x3_mx(dq, ds, mx, None, None, pair[2] if pair is not None else 0, dx, spec.cin, L.PAD_ZERO, L.GATHER_TRANSPOSED,
-                        L.ACT_NONE, 0.0, None, bord, res_add)
+                        L.ACT_NONE, 0.0, None, bord, res_add, bst)
         else:
             _gather(dy, wp_dgrad, None, dx, B, Ho, Wo, Cd, spec.cin, spec, 1, 1, L.PAD_ZERO, L.GATHER_TRANSPOSED, H, W, spec.cin_p,
-                    L.ACT_NONE, 0.0, "uig_conv_gather(dgrad+border)", pair, None, bord, res_add)
+                    L.ACT_NONE, 0.0, "uig_conv_gather(dgrad+border)", pair, None, bord, res_add, bst)
+        if bpart is not None:
+            dx._uig_bst_partial = (bpart, H * W // 64)
         return dx
     if spec.reflect:             # gradient w.r.t. the reflection-padded input, then fold the border back
         P = spec.pad
@@ -558,7 +583,7 @@ def _conv_backward(ctx, dy, layers, group):
         skip, link.grad = link.grad, None
     dx = None
     if need_x and not par:
-        dx = conv_dgrad(spec, dy, layers[0].wp_dgrad, ctx.in_hw, pair, skip, mx=mx)
+        dx = conv_dgrad(spec, dy, layers[0].wp_dgrad, ctx.in_hw, pair, skip, mx=mx, bst=getattr(ctx, "bst", None))
     grads = []
     if par:
         side = _side_stream(dy.device)
@@ -577,7 +602,7 @@ def _conv_backward(ctx, dy, layers, group):
             grads.extend(_param_grads(layer, spec, xs, dys, need_w[i], need_b[i], colsum, i0, pparts[i] if pparts else None))
     if par:
         if need_x:
-            dx = conv_dgrad(spec, dy, layers[0].wp_dgrad, ctx.in_hw, pair, skip, mx=mx)
+            dx = conv_dgrad(spec, dy, layers[0].wp_dgrad, ctx.in_hw, pair, skip, mx=mx, bst=getattr(ctx, "bst", None))
         if defer:
             # no join here: the side stream keeps working behind the main stream's next ops (InstanceNorm backward, the next
             # layer's input gradient, ...).  The tensors it reads are pinned for the allocator with record_stream; the owner
@@ -601,6 +626,7 @@ class ConvFn(Function):
         mx = (layer.wq_fwd, layer.ws_fwd) if layer.mx_active(x.shape[0], x.shape[1], x.shape[2]) else None
         y = conv_forward(spec, x, layer.wp_fwd, bias, want_in_stats=layer.emit_in_stats, mx=mx)
         ctx.layer, ctx.in_hw, ctx.skip_link = layer, (x.shape[1], x.shape[2]), skip_link
+        ctx.bst = getattr(x, "_uig_bst", None)      # x is the output of an InstanceNorm: (its input, its stats, act, slope)
         ctx.save_for_backward(x, y if spec.act != L.ACT_NONE else None)
         return y
 
@@ -622,6 +648,7 @@ class PairConvFn(Function):
             mx = (layer1.wq_fwd, layer1.ws_fwd, layer2.wq_fwd, layer2.ws_fwd)
         y = conv_forward(spec, x, layer1.wp_fwd, b1, pair=(layer2.wp_fwd, b2, group), want_in_stats=layer1.emit_in_stats, mx=mx)
         ctx.layers, ctx.group, ctx.in_hw, ctx.skip_link = (layer1, layer2), group, (x.shape[1], x.shape[2]), skip_link
+        ctx.bst = getattr(x, "_uig_bst", None)
         ctx.save_for_backward(x, y if spec.act != L.ACT_NONE else None)
         return y
 
@@ -689,6 +716,10 @@ class InstNormActFn(Function):
                                              _dt(x), _stream()), "uig_instnorm_act_fwd")
         ctx.act, ctx.slope, ctx.has_res, ctx.skip_link = act, slope, residual is not None, skip_link
         ctx.save_for_backward(x, stats)
+        if FUSE_BWD_STATS and ctx.needs_input_grad[0]:
+            # the convolution that consumes y produces this norm's dy in its input-gradient launch: hand it what that launch needs
+            # to emit this norm's backward statistics from its epilogue (conv_dgrad / StripDesc::bst_*)
+            y._uig_bst = (x, stats, act, slope)
         return y
 
     @staticmethod
@@ -713,7 +744,17 @@ def instnorm_backward(dy, x, stats, act, slope, emit_mx=False):
     dx = torch.empty_like(x)
     slabs = int(lib.uig_instnorm_bwd_colsum_slabs(B, H * W, C, _dt(x)))
     cpart = torch.empty((slabs * C * 2,), device=x.device, dtype=torch.float32)
-    if emit_mx:      # dx is the dy of an fp8 convolution: its MX form comes out of the same launch
+    pre = getattr(dy, "_uig_bst_partial", None)
+    if pre is not None and pre[0].numel() == B * pre[1] * C * 2:      # statistics already produced by the launch that wrote dy
+        q = s = None
+        if emit_mx:
+            q = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+            s = torch.empty((B, H, W, C // 32), device=x.device, dtype=torch.uint8)
+        L.check(lib.uig_instnorm_act_bwd_colsum_pre(_p(dy), _p(x), _p(stats), _p(dx), _p(ws), _p(cpart), _p(pre[0]), pre[1], _p(q), _p(s),
+                                                    B, H * W, C, act, slope, _dt(x), _stream()), "uig_instnorm_act_bwd_colsum_pre")
+        if emit_mx:
+            dx._uig_mx = (q, s)
+    elif emit_mx:      # dx is the dy of an fp8 convolution: its MX form comes out of the same launch
         q = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
         s = torch.empty((B, H, W, C // 32), device=x.device, dtype=torch.uint8)
         L.check(lib.uig_instnorm_act_bwd_colsum_mx(_p(dy), _p(x), _p(stats), _p(dx), _p(ws), _p(cpart), _p(q), _p(s), B, H * W, C, act, slope,
