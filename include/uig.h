@@ -36,8 +36,8 @@ enum { UIG_PACK_ROW_DIM0 = 0, UIG_PACK_ROW_DIM1 = 1 };
 const char* uig_version(void);
 const char* uig_last_error(void);
 int uig_device_ok(void); /* 1 if a gfx950 device is visible to the HIP runtime */
-/* test hook: the kernel family the calling thread's last uig_conv_gather* launch ran on, so that a parity test can assert it
- * covers the kernel it means to cover rather than a fallback */
+/* test hook: the kernel family the process's last uig_conv_gather* launch ran on (any thread: autograd's backward thread
+ * included), so that a parity test can assert it covers the kernel it means to cover rather than a fallback */
 enum { UIG_K_NONE = 0, UIG_K_IGEMM = 1, UIG_K_STRIP128 = 2, UIG_K_STRIP256 = 3, UIG_K_STRIP_PK = 4, UIG_K_ROWSTRIP = 5,
        UIG_K_HEADROW = 6, UIG_K_GEMV = 7, UIG_K_CIN8 = 8, UIG_K_TR2 = 9 };
 int uig_debug_last_conv_kernel(void);

@@ -22,6 +22,10 @@ def _bf(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+def Wo_of(W, k, s, p):
+    return (W + 2 * p - k) // s + 1
+
+
 def _tol(dtype, ref):
     scale = float(ref.abs().max()) + 1e-6
     return (2e-5 * scale + 1e-6) if dtype == torch.float32 else (1.6e-2 * scale)
@@ -46,6 +50,9 @@ CONV_CASES = [
     ("conv", 3, 64, 7, 1, 3, "reflect", 40, 256, 2),    # G stem at the benchmark's row width: bf16 -> conv_cin8 (LDS-resident weights)
     ("conv", 3, 64, 7, 1, 3, "reflect", 24, 232, 1),    # ... ragged second 128-pixel segment
     ("conv", 64, 3, 7, 1, 3, "reflect", 24, 256, 2),    # G head at the benchmark's row width: bf16 -> taps-on-N head-row kernel
+    ("convT", 256, 128, 3, 2, 1, "zero", 8, 64, 2),     # G up1 at its real row width: bf16 -> phase-fused transposed kernel (conv_tr2), vs the ORACLE
+    ("convT", 128, 64, 3, 2, 1, "zero", 4, 128, 1),     # G up2 at its real row width (conv_tr2)
+    ("conv", 64, 128, 3, 2, 1, "zero", 16, 128, 2),     # G down1: its input gradient (dy 8x64) runs on conv_tr2
 ]
 
 
@@ -73,6 +80,8 @@ def test_conv_fwd_bwd(case, dtype):
     if dtype == torch.bfloat16 and W >= 232 and k == 7:      # the wide-row cases exist to cover these two kernels: fail if dispatch changes
         want = u.lib.K_CIN8 if cin == 3 else u.lib.K_HEADROW
         assert u.lib.lib().uig_debug_last_conv_kernel() == want, u.lib.lib().uig_debug_last_conv_kernel()
+    if dtype == torch.bfloat16 and kind == "convT" and W in (64, 128):
+        assert u.lib.lib().uig_debug_last_conv_kernel() == u.lib.K_TR2
     y = ops.from_nhwc(yp, cout).cpu()
     assert y.shape == yref.shape
     assert (y - yref.detach()).abs().max() <= _tol(dtype, yref), f"fwd L-inf {(y - yref.detach()).abs().max()}"
@@ -84,6 +93,8 @@ def test_conv_fwd_bwd(case, dtype):
     yref.backward(dyr)
     dyp = ops.to_nhwc(dy.cuda(), dtype, yp.shape[3])
     yp.backward(dyp)
+    if dtype == torch.bfloat16 and kind == "conv" and s == 2 and k == 3 and Wo_of(W, k, s, p) in (64, 128):
+        assert u.lib.lib().uig_debug_last_conv_kernel() == u.lib.K_TR2      # the stride-2 conv's input gradient ran on conv_tr2
     dx = ops.from_nhwc(xp.grad, cin).cpu()
     assert (dx - xr.grad).abs().max() <= _tol(dtype, xr.grad), f"dgrad L-inf {(dx - xr.grad).abs().max()}"
     if xp.grad.shape[3] > cin:
