@@ -230,7 +230,7 @@ def test_train_step_gradients_vs_oracle_fp32():
 def test_generator_shapes_fwd_bwd_fp32(B, H, W):
     """Shape sweep (tiny / non-square / odd tile counts / batch 1 and 3): generator forward L-inf < 1e-3 and the input
     gradient + every weight gradient vs the oracle.  Exercises the strip / generic / border / fold fallbacks.
-    Gradient tolerance: relative L2 < 1e-2.  Per operator the HIP kernels agree with the oracle to ~1e-6 (scripts/diag_*.py);
+    Gradient tolerance: relative L2 < 1e-2.  Per operator the HIP kernels agree with the oracle to ~1e-6 (tests/test_ops_gpu.py, fp32 cases);
     through the network a handful of pre-activations lie within rounding distance of 0, the ReLU mask of those elements
     flips between two correct fp32 evaluations and everything below inherits an O(1e-3) relative difference - the fp32
     oracle differs from the fp64 oracle by 8e-4 / 1.2e-3 on the 64x64 / 128x128 cases here, and by 1e-6 at 32x32."""
