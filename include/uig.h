@@ -181,6 +181,16 @@ int uig_wgrad_pair_splits(int B, int group_images, int Mh, int Mw, int Np, int H
 int uig_wgrad_partial_pair(const void* P, const void* Q, float* workspace, int B, int group_images, int Mh, int Mw,
                            int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int pad_mode,
                            int splits, int dtype, void* stream);
+/* The same over TWO batches in one launch: the step's two generator passes use the same two weight sets - pass 1 on (P, Q) =
+ * B1 images of which the first g1 are network 0's, pass 2 on (P2, Q2) = B2 images of which the first g2 are network
+ * (swap2 ? 1 : 0)'s.  The fixed cost of a split-K launch (fill / drain, partial slabs, reduce) is paid once.
+ * uig_wgrad_pair2_splits: split count to use, 0 = the image-row kernel does not take this shape (run the two launches).
+ * Workspace and reduce as for uig_wgrad_partial_pair. */
+int uig_wgrad_pair2_splits(int B1, int g1, int B2, int g2, int swap2, int Mh, int Mw, int Np, int Hq, int Wq, int Cq,
+                           int kH, int kW, int stride, int pad, int dtype);
+int uig_wgrad_partial_pair2(const void* P, const void* Q, const void* P2, const void* Q2, float* workspace,
+                            int B1, int g1, int B2, int g2, int swap2, int Mh, int Mw, int Np, int Hq, int Wq, int Cq,
+                            int kH, int kW, int stride, int pad, int pad_mode, int splits, int dtype, void* stream);
 /* both halves of a uig_wgrad_partial_pair workspace in one launch (colsum_* NULL = no bias gradient on this launch) */
 int uig_wgrad_reduce_pair(const float* workspace, float* dW_a, float* dW_b, int Np, int Cq, int taps, int splits,
                           int D0, int D1, int accumulate, const float* colsum_a, const float* colsum_b,

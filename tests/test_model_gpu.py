@@ -420,6 +420,42 @@ def test_staged_backward_step_equals_single_stage(graph):
     m0.close(); m1.close()
 
 
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
+def test_combined_pass_weight_gradient_equals_separate(graph, monkeypatch):
+    """The generator phase's weight gradients with ONE launch per ResBlock conv pair for both generator passes
+    (ops.combined_pass_wgrad, the default) against one launch per pass: the same sums in another order - fp32 partials, so the
+    flat gradient buffer agrees to ~1e-6 of its scale after the first step, and the losses of the next steps stay together."""
+    import unpaired_image_generation_amd as u
+    ops = u.ops
+    torch.manual_seed(22)
+    rA, rB = (torch.rand(2, 3, 32, 256, device="cuda") * 2 - 1 for _ in range(2))     # 64-pixel-wide ResBlock maps: the image-row kernel's shape
+    torch.manual_seed(6)
+    monkeypatch.setattr(ops, "COMBINE_PASS_WGRAD", False)
+    m0 = u.CycleGAN(n_blocks=3, dtype=torch.bfloat16, use_graph=graph, stage_backward=True)
+    l0 = [m0.train_step(rA, rB) for _ in range(1)]
+    g0 = m0.grp_G.grad.clone()
+    l0 += [m0.train_step(rA, rB) for _ in range(2)]
+    monkeypatch.setattr(ops, "COMBINE_PASS_WGRAD", True)
+    torch.manual_seed(6)
+    m1 = u.CycleGAN(n_blocks=3, dtype=torch.bfloat16, use_graph=graph, stage_backward=True)
+    seen = []
+    real = ops._combined_wgrad
+    monkeypatch.setattr(ops, "_combined_wgrad", lambda *a: (seen.append(real(*a)) or seen[-1]))
+    l1 = [m1.train_step(rA, rB) for _ in range(1)]
+    g1 = m1.grp_G.grad.clone()
+    l1 += [m1.train_step(rA, rB) for _ in range(2)]
+    assert not ops._WG_STASH, "the region must be closed (and its stash flushed) after the step"
+    # every ResBlock conv pair of every Python-level backward (3 eager steps; warm-up + capture in graph mode): stashed on the
+    # first visit, combined on the second
+    assert sum(seen) >= 4 * 3 and sum(seen) % (4 * 3) == 0, sum(seen)
+    scale = float(g0.abs().max())
+    assert float((g0 - g1).abs().max()) <= 2e-5 * scale
+    for a, b in zip(l0, l1):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-3 * max(1.0, abs(a[k])), (k, a[k], b[k])
+    m0.close(); m1.close()
+
+
 def test_graph_step_with_rccl_exchange_world1_and_close():
     """Guards two aborts seen in round 1 (graph capture with a live process group; process exit with graphs + RCCL alive).
     One worker process = one rank, as in production (the process group lives as long as the process):

@@ -273,6 +273,38 @@ def test_wgrad_pair_launch_matches_single():
             assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (kind, cin, cout, k)
 
 
+@pytest.mark.parametrize("swap2", [0, 1])
+def test_wgrad_two_batch_launch_matches_single(swap2):
+    """the generator phase's combined launch (ops.combined_pass_wgrad): pass 1's batch (3 + 2 images for networks A / B) and pass 2's
+    batch (2 + 1 images, with swap2 in the order B / A) reduced into ONE pair of partial slabs, against the sum of one launch per
+    network and batch"""
+    u, ops, networks = _mods()
+    L = u.lib
+    lib = L.lib()
+    torch.manual_seed(40 + swap2)
+    layer = networks.ConvLayer("conv", 128, 256, 3, 1, 1, "reflect", dtype=torch.bfloat16, device="cuda")
+    spec = layer.spec
+    x1 = (torch.rand(5, 64, 64, 128, device="cuda") * 2 - 1).to(torch.bfloat16)
+    dy1 = (torch.randn(5, 64, 64, 256, device="cuda") * 0.5).to(torch.bfloat16)
+    x2 = (torch.rand(3, 64, 64, 128, device="cuda") * 2 - 1).to(torch.bfloat16)
+    dy2 = (torch.randn(3, 64, 64, 256, device="cuda") * 0.5).to(torch.bfloat16)
+    g1, g2 = 3, 2
+    args = (64, 64, 256, 64, 64, 128, 3, 3, 1, 1)
+    splits = int(lib.uig_wgrad_pair2_splits(5, g1, 3, g2, swap2, *args, L.BF16))
+    assert splits > 0, "the image-row kernel should take this shape"
+    per = splits * 256 * 9 * 128
+    ws = torch.empty((2 * per,), device="cuda", dtype=torch.float32)
+    s = torch.cuda.current_stream().cuda_stream
+    L.check(lib.uig_wgrad_partial_pair2(dy1.data_ptr(), x1.data_ptr(), dy2.data_ptr(), x2.data_ptr(), ws.data_ptr(), 5, g1, 3, g2, swap2,
+                                        *args, L.PAD_REFLECT, splits, L.BF16, s), "uig_wgrad_partial_pair2")
+    a2, b2 = (slice(g2, 3), slice(0, g2)) if swap2 else (slice(0, g2), slice(g2, 3))      # pass 2's images of network A / B
+    for part, s1, s2 in (((ws[:per], splits), slice(0, g1), a2), ((ws[per:], splits), slice(g1, 5), b2)):
+        got = ops.conv_wgrad(spec, x1[s1], dy1[s1], partial=part)
+        ref = ops.conv_wgrad(spec, x1[s1], dy1[s1]) + ops.conv_wgrad(spec, x2[s2], dy2[s2])
+        torch.cuda.synchronize()
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("act", ["tanh", "lrelu"])
 def test_conv_epilogue_activation(act, dtype):

@@ -445,6 +445,37 @@ extern "C" int uig_wgrad_partial_pair(const void* P, const void* Q, float* works
     return wgrad_partial_impl(P, Q, workspace, B, group_images, Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, pad_mode, splits, dtype, stream);
 }
 
+// The weight gradient of one layer pair over TWO batches in one launch (round 2): the step's two generator passes use the same
+// two weight sets, pass 1 on (P, Q) = B1 images of which the first g1 are network 0's, pass 2 on (P2, Q2) = B2 images of which
+// the first g2 are network (swap2 ? 1 : 0)'s.  One launch instead of two: the fixed cost of a split-K launch (fill / drain, the
+// partial slabs and their reduce) is paid once - measured 147 us against 111 + 74 us for 16 + 8 images incl. the reduce.
+// Only for shapes the image-row kernel takes (uig_wgrad_pair2_splits returns 0 otherwise: run the two launches).
+// Workspace: [2][splits][Np][9*Cq] floats, reduced like uig_wgrad_partial_pair's.
+int uig_launch_wgrad_rows_runs(const void* P, const void* Q, const void* P2, const void* Q2, float* ws, int B1, int B2, int H, int Np, int Cq,
+                               int pad_mode, int splits, const int* imgs, const int* img0, const int* sel, hipStream_t s);
+extern "C" int uig_wgrad_pair2_splits(int B1, int g1, int B2, int g2, int swap2, int Mh, int Mw, int Np, int Hq, int Wq, int Cq,
+                                      int kH, int kW, int stride, int pad, int dtype) {
+    if (g1 <= 0 || g1 >= B1 || g2 <= 0 || g2 >= B2) return 0;
+    if (!uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype)) return 0;
+    const int n0 = g1 + (swap2 ? B2 - g2 : g2), n1 = (B1 - g1) + (swap2 ? g2 : B2 - g2);
+    if ((long)(B1 + B2) * Mh * Mw * std::max(Np, Cq) * 2 >= (1L << 32) - 64) return 0;
+    return (int)std::max<long>(1, std::min<long>(256 / (2 * uig_wgrad_rows_tiles(Np, Cq)), (long)std::min(n0, n1) * Mh));
+}
+extern "C" int uig_wgrad_partial_pair2(const void* P, const void* Q, const void* P2, const void* Q2, float* workspace,
+                                       int B1, int g1, int B2, int g2, int swap2, int Mh, int Mw, int Np, int Hq, int Wq, int Cq,
+                                       int kH, int kW, int stride, int pad, int pad_mode, int splits, int dtype, void* stream) {
+    UIG_CHECK_ARG(P && Q && P2 && Q2 && workspace, "uig_wgrad_partial_pair2: null pointer");
+    UIG_CHECK_ARG(uig_wgrad_pair2_splits(B1, g1, B2, g2, swap2, Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype) > 0,
+                  "uig_wgrad_partial_pair2: shape not supported by the image-row kernel (query uig_wgrad_pair2_splits)");
+    const int n0 = g1 + (swap2 ? B2 - g2 : g2), n1 = (B1 - g1) + (swap2 ? g2 : B2 - g2);
+    UIG_CHECK_ARG(splits >= 1 && splits <= std::min(n0, n1) * Mh, "uig_wgrad_partial_pair2: bad splits %d", splits);
+    // network 0: pass-1 images [0, g1), then pass-2's share; network 1: pass-1 images [g1, B1), then pass-2's share
+    const int imgs[4] = {g1, swap2 ? B2 - g2 : g2, B1 - g1, swap2 ? g2 : B2 - g2};
+    const int img0[4] = {0, swap2 ? g2 : 0, g1, swap2 ? 0 : g2};
+    const int sel[4] = {0, 1, 0, 1};
+    return uig_launch_wgrad_rows_runs(P, Q, P2, Q2, workspace, B1, B2, Mh, Np, Cq, pad_mode, splits, imgs, img0, sel, (hipStream_t)stream);
+}
+
 static int wgrad_reduce_impl(const float* workspace, float* dW, int Np, int Cq, int taps, int splits, int D0, int D1, int accumulate,
                              BiasRider br, void* stream, float* dW2 = nullptr, BiasRider br2 = BiasRider{nullptr, nullptr, 0, 0, 0, 0, 0}) {
     UIG_CHECK_ARG(workspace && dW, "uig_wgrad_reduce: null pointer");

@@ -27,6 +27,13 @@ struct WgRowsDesc {
     int group_rows;          // two networks in one launch: image rows [0, group_rows) are network 0's, the rest network 1's
                              // (0 = one network); partial slabs are laid out [network][split][Np][ncols]
     unsigned p_bytes, q_bytes;
+    // The image rows of a network are up to two RUNS of whole images, each in one of two operand tensor pairs (round 2: the
+    // weight gradient of BOTH generator passes of a step in one launch - pass 1's batch lives in (P, Q), pass 2's in (P2, Q2)).
+    // Runs 0, 1 = network 0's, runs 2, 3 = network 1's, walked in this order; group_rows = run_rows[0] + run_rows[1].
+    int run_rows[4];         // image rows (images * H) of each run; 0 = empty
+    int run_img0[4];         // first image of the run inside its tensor
+    int run_sel[4];          // 0: (P, Q), 1: (P2, Q2)
+    unsigned p2_bytes, q2_bytes;
 };
 
 namespace {
@@ -37,6 +44,7 @@ constexpr int WR_NST = 4;
 }
 
 __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __restrict__ P, const bf16_t* __restrict__ Q,
+                                                               const bf16_t* __restrict__ P2, const bf16_t* __restrict__ Q2,
                                                                float* __restrict__ part, const WgRowsDesc d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
@@ -66,29 +74,47 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
     // ---- DMA: wave w stages pieces w and w+8 (rows 4w..4w+3 and +32) of both tiles
     const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(P), 0, d.p_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Q), 0, d.q_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsP2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(P2 ? P2 : P), 0, P2 ? d.p2_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsQ2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Q2 ? Q2 : Q), 0, Q2 ? d.q2_bytes : 0u, 0x00020000);
     const int ra = 4 * wave + (lane >> 4);                            // pixel (LDS row) this lane fills in piece w
     const int chunk = (lane & 15) ^ ((ra & 7) << 1);                  // source chunk for LDS slot lane&15 (same for row ra+32)
     const unsigned voffP = (unsigned)((ra * d.Np + n_base + chunk * 8) * 2);
     const unsigned voffQ = (unsigned)((ra * d.Cq + ci_base + chunk * 8) * 2);
     const bool refl = d.pad_mode == UIG_PAD_REFLECT;
-    int ib = row_begin / d.H, ii = row_begin % d.H;                   // (image, row) of the next K-step to issue
-    int Rn = row_begin;
+    // (tensor, image, row) of the next K-step to issue: the network's rows are run 2*net followed by run 2*net+1 (whole images)
+    const int run_a = 2 * net, a_rows = d.run_rows[run_a];
+    const int l0 = row_begin - net_row0;                              // row inside the network
+    const bool in_a = l0 < a_rows;
+    const int loc0 = in_a ? l0 : l0 - a_rows;
+    int sel = d.run_sel[in_a ? run_a : run_a + 1];
+    int ib = d.run_img0[in_a ? run_a : run_a + 1] + loc0 / d.H, ii = loc0 % d.H;
+    int left = in_a ? a_rows - l0 : 0x7fffffff;                      // rows until the switch to the second run
+    const int nx_sel = d.run_sel[run_a + 1], nx_img0 = d.run_img0[run_a + 1];
     auto issue = [&](int stage) {
         const int hi = ii + kh - 1;
         const bool valid = refl | ((unsigned)hi < (unsigned)d.H);
         const int hr = refl ? reflect_idx(hi, d.H) : (valid ? hi : 0);
-        const int sP = __builtin_amdgcn_readfirstlane((int)((unsigned)Rn * (unsigned)(WR_W * 2) * (unsigned)d.Np));
+        const int sP = __builtin_amdgcn_readfirstlane((int)((unsigned)(ib * d.H + ii) * (unsigned)(WR_W * 2) * (unsigned)d.Np));
         const int sQ = __builtin_amdgcn_readfirstlane((int)((unsigned)(ib * d.H + hr) * (unsigned)(WR_W * 2) * (unsigned)d.Cq));
         const unsigned vq = valid ? voffQ : 0xFFFFFFFFu;              // zero-padded row: out-of-range offset -> zeros
         lds_ptr_t dst = (lds_ptr_t)smem + stage * WR_STAGE + wave * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (__attribute__((address_space(3))) void*)dst, 16, (int)voffP, sP, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (__attribute__((address_space(3))) void*)(dst + 8192), 16, (int)voffP,
-                                                 sP + 32 * d.Np * 2, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(dst + WR_TILE), 16, (int)vq, sQ, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(dst + WR_TILE + 8192), 16, (int)vq,
-                                                 sQ + 32 * d.Cq * 2, 0, 0);
-        ++Rn;
+        if (__builtin_amdgcn_readfirstlane(sel) == 0) {               // block-uniform
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (__attribute__((address_space(3))) void*)dst, 16, (int)voffP, sP, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (__attribute__((address_space(3))) void*)(dst + 8192), 16, (int)voffP,
+                                                     sP + 32 * d.Np * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(dst + WR_TILE), 16, (int)vq, sQ, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(dst + WR_TILE + 8192), 16, (int)vq,
+                                                     sQ + 32 * d.Cq * 2, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP2, (__attribute__((address_space(3))) void*)dst, 16, (int)voffP, sP, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP2, (__attribute__((address_space(3))) void*)(dst + 8192), 16, (int)voffP,
+                                                     sP + 32 * d.Np * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ2, (__attribute__((address_space(3))) void*)(dst + WR_TILE), 16, (int)vq, sQ, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ2, (__attribute__((address_space(3))) void*)(dst + WR_TILE + 8192), 16, (int)vq,
+                                                     sQ + 32 * d.Cq * 2, 0, 0);
+        }
         if (++ii == d.H) { ii = 0; ++ib; }
+        if (--left == 0) { sel = nx_sel; ib = nx_img0; ii = 0; left = 0x7fffffff; }
     };
 
     // ---- fragment addressing (stage-relative byte offsets).  Wave (wn, wc): 64 co x 32 ci x 3 kw.
@@ -270,20 +296,35 @@ bool uig_wgrad_rows_applicable(int Mh, int Mw, int Np, int Hq, int Wq, int Cq, i
 
 int uig_wgrad_rows_tiles(int Np, int Cq) { return (Np / 128) * (Cq / 128) * 3; }
 
-int uig_launch_wgrad_rows(const void* P, const void* Q, float* ws, int B, int H, int Np, int Cq, int pad_mode, int splits,
-                          int group_images, hipStream_t s) {
+// General form: up to two runs of whole images per network, each in (P, Q) [sel 0] or (P2, Q2) [sel 1]; imgs[r] images starting
+// at image img0[r] of its tensor; runs 0, 1 are network 0's, runs 2, 3 network 1's (one network: runs 2, 3 empty).
+// B1 / B2 = images in (P, Q) / (P2, Q2) (for the range checks of the buffer descriptors).
+int uig_launch_wgrad_rows_runs(const void* P, const void* Q, const void* P2, const void* Q2, float* ws, int B1, int B2, int H, int Np, int Cq,
+                               int pad_mode, int splits, const int* imgs, const int* img0, const int* sel, hipStream_t s) {
     WgRowsDesc d{};
-    d.group_rows = group_images * H;
-    d.B = B; d.H = H; d.Np = Np; d.Cq = Cq; d.pad_mode = pad_mode; d.ncols = 9 * Cq; d.rows_total = B * H;
+    int total = 0;
+    for (int r = 0; r < 4; ++r) { d.run_rows[r] = imgs[r] * H; d.run_img0[r] = img0[r]; d.run_sel[r] = sel[r]; total += imgs[r]; }
+    const bool two = imgs[2] + imgs[3] > 0;
+    d.group_rows = two ? d.run_rows[0] + d.run_rows[1] : 0;
+    d.B = total; d.H = H; d.Np = Np; d.Cq = Cq; d.pad_mode = pad_mode; d.ncols = 9 * Cq; d.rows_total = total * H;
     d.ntc = Cq / 128; d.ntiles = uig_wgrad_rows_tiles(Np, Cq); d.splits = splits;
-    d.p_bytes = (unsigned)((long)B * H * WR_W * Np * 2); d.q_bytes = (unsigned)((long)B * H * WR_W * Cq * 2);
+    d.p_bytes = (unsigned)((long)B1 * H * WR_W * Np * 2); d.q_bytes = (unsigned)((long)B1 * H * WR_W * Cq * 2);
+    d.p2_bytes = (unsigned)((long)B2 * H * WR_W * Np * 2); d.q2_bytes = (unsigned)((long)B2 * H * WR_W * Cq * 2);
     const size_t smem = (size_t)WR_NST * WR_STAGE;
     static SmemAttrOnce attr_once;
     {
         hipError_t e = attr_once.ensure(reinterpret_cast<const void*>(wgrad_rows3_kernel), (size_t)(int)smem);
         if (e != hipSuccess) return uig_set_error((int)e, "wgrad(rows): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(wgrad_rows3_kernel, dim3(d.ntiles * splits * (group_images > 0 ? 2 : 1)), dim3(512), smem, s, (const bf16_t*)P, (const bf16_t*)Q, ws, d);
+    hipLaunchKernelGGL(wgrad_rows3_kernel, dim3(d.ntiles * splits * (two ? 2 : 1)), dim3(512), smem, s, (const bf16_t*)P, (const bf16_t*)Q,
+                       (const bf16_t*)P2, (const bf16_t*)Q2, ws, d);
     UIG_LAUNCH_CHECK("uig_wgrad_partial(rows)");
     return 0;
+}
+
+int uig_launch_wgrad_rows(const void* P, const void* Q, float* ws, int B, int H, int Np, int Cq, int pad_mode, int splits,
+                          int group_images, hipStream_t s) {
+    const int imgs[4] = {group_images > 0 ? group_images : B, 0, group_images > 0 ? B - group_images : 0, 0};
+    const int img0[4] = {0, 0, group_images, 0}, sel[4] = {0, 0, 0, 0};
+    return uig_launch_wgrad_rows_runs(P, Q, nullptr, nullptr, ws, B, 0, H, Np, Cq, pad_mode, splits, imgs, img0, sel, s);
 }

@@ -175,14 +175,16 @@ class CycleGAN:
         res.update(fake_B=fake_B.detach(), fake_A=fake_A.detach(), losses=losses)
         self.last_fake_B = res["fake_B"]
         ctx = (lambda k: ops.deferred_param_grads(self.device)) if self.defer_join else None
-        if taps:
-            # pass 1 (the 4B-image pass) is the LAST part of the backward pass and a chain through its ResBlocks: cut there
-            cuts = [taps[i] for i in self.cuts_G]
-            yield from staged_backward(losses, cuts, self._stage_params((self.G_A, self.G_B), self.cuts_G), ctx)
-        else:
-            with ctx(0) if ctx else contextlib.nullcontext():
-                ops.backward_unit(losses)
-            yield 0
+        # both generator passes back-propagate through the same layer pairs: one weight-gradient launch per pair for both batches
+        with ops.combined_pass_wgrad(self.device) if (self.batch_fused and self.paired) else contextlib.nullcontext():
+            if taps:
+                # pass 1 (the 4B-image pass) is the LAST part of the backward pass and a chain through its ResBlocks: cut there
+                cuts = [taps[i] for i in self.cuts_G]
+                yield from staged_backward(losses, cuts, self._stage_params((self.G_A, self.G_B), self.cuts_G), ctx)
+            else:
+                with ctx(0) if ctx else contextlib.nullcontext():
+                    ops.backward_unit(losses)
+                yield 0
         self.grp_D.set_requires_grad(True)
 
     def _d_phase(self, xa, xb, fake_B, fake_A):

@@ -57,6 +57,8 @@ SIGNATURES = {
     "uig_wgrad_partial": (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp]),
     "uig_wgrad_pair_splits": (_i, [_i] * 14),
     "uig_wgrad_partial_pair": (_i, [_vp, _vp, _vp] + [_i] * 15 + [_vp]),
+    "uig_wgrad_pair2_splits": (_i, [_i] * 16),
+    "uig_wgrad_partial_pair2": (_i, [_vp] * 5 + [_i] * 18 + [_vp]),
     "uig_wgrad_reduce_pair": (_i, [_vp, _vp, _vp] + [_i] * 7 + [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "uig_wgrad_reduce": (_i, [_vp, _vp] + [_i] * 7 + [_vp]),
     "uig_wgrad_reduce_bias": (_i, [_vp, _vp] + [_i] * 7 + [_vp, _i, _i, _i, _vp, _i, _vp]),

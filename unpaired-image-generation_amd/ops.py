@@ -27,8 +27,10 @@ PARALLEL_BACKWARD = os.environ.get("UIG_PARALLEL_BACKWARD", "1") != "0"      # r
 # convolution's critical path, while the stand-alone pass is HBM-bound at full occupancy.  Tested opt-in (test_ops_gpu.py).
 FUSE_BWD_STATS = os.environ.get("UIG_FUSE_BWD_STATS", "0") != "0"
 FUSE_MX_QUANT = os.environ.get("UIG_FUSE_MX_QUANT", "1") != "0"            # fp8 path: MX quantisation of activations / gradients inside the InstanceNorm launches
+COMBINE_PASS_WGRAD = os.environ.get("UIG_COMBINE_PASS_WGRAD", "1") != "0"  # one weight-gradient launch per ResBlock conv pair for BOTH generator passes of a step
 _SIDE_STREAMS = {}
 _DEFER_JOIN = {}
+_WG_STASH = {}          # device index -> {layer pair: (x, dy, group, layers)} while a combined_pass_wgrad region is active
 
 
 def _side_stream(device) -> torch.cuda.Stream:
@@ -42,6 +44,82 @@ def _side_stream(device) -> torch.cuda.Stream:
 def release_side_streams(device) -> None:
     """forget the parameter-gradient side stream of `device` (CycleGAN.close(): ordered teardown)"""
     _SIDE_STREAMS.pop(torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), None)
+
+
+class combined_pass_wgrad:
+    """Region (the generator phase's backward pass) in which a layer pair that is back-propagated TWICE - the step's two generator
+    passes run the same two weight sets, the second pass's backward first - gets ONE weight-gradient launch for both batches:
+    the first visit stashes its (x, dy) and only settles the bias gradient, the second visit runs uig_wgrad_partial_pair2 over
+    both batches and the usual paired reduce.  The fixed cost of a split-K launch (fill / drain, partial slabs, reduce) is paid
+    once per layer instead of twice: 147 us against 111 + 74 us per ResBlock conv pair at batch 4 (scripts/bench_wgrad_combine.py).
+    Anything still stashed on exit (a pair visited once) is flushed with an ordinary launch."""
+
+    def __init__(self, device):
+        self.idx = torch.device(device).index
+        if self.idx is None:
+            self.idx = torch.cuda.current_device()
+
+    def __enter__(self):
+        if COMBINE_PASS_WGRAD:
+            _WG_STASH[self.idx] = {}
+        return self
+
+    def __exit__(self, *exc):
+        st = _WG_STASH.pop(self.idx, None)
+        if st:
+            side = _side_stream(torch.device("cuda", self.idx))
+            main = torch.cuda.current_stream(self.idx)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for x, dy, group, layers in st.values():
+                    pp = conv_wgrad_pair_partial(layers[0].spec, x, dy, group)
+                    if not (pp and _param_grads_pair(layers, layers[0].spec, x, dy, group, None, pp, bias=False)):
+                        for i, l in enumerate(layers):
+                            xs, dys = (x[:group], dy[:group]) if i == 0 else (x[group:], dy[group:])
+                            conv_wgrad(l.spec, xs, dys, out=l.weight.grad, accumulate=True)
+            main.wait_stream(side)
+        return False
+
+
+def _combined_wgrad(layers, spec, x, dy, group, colsum, stash):
+    """weight (+ bias) gradients of a layer pair inside a combined_pass_wgrad region; returns False if the ordinary path must run"""
+    lib = L.lib()
+    key = frozenset((id(layers[0]), id(layers[1])))
+    Pt, Qt, Mh, Mw, Np, Hq, Wq, Cq, pm, D0, D1 = _wgrad_operands(spec, x, dy)
+    B = x.shape[0]
+    prev = stash.pop(key, None)
+    if prev is None:
+        if int(lib.uig_wgrad_pair2_splits(B, group, B, group, 0, Mh, Mw, Np, Hq, Wq, Cq, spec.k, spec.k, spec.stride, spec.pad, _dt(x))) <= 0:
+            return False
+        # first visit (the later pass): the bias gradient now, the weight gradient together with the other pass's batch
+        for i, l in enumerate(layers):
+            dys, i0 = (dy[:group], 0) if i == 0 else (dy[group:], group)
+            if colsum is not None and colsum[2] == dy.shape[3]:
+                _bias_grad_from_partials(colsum, i0, dys.shape[0], spec.cout, l.bias.grad, True)
+            else:
+                bias_grad(dys, spec.cout, out=l.bias.grad, accumulate=True)
+        stash[key] = (x, dy, group, layers)
+        return True
+    x2, dy2, g2, layers2 = prev
+    swap2 = 1 if layers2[0] is layers[1] else 0
+    P2, Q2 = _wgrad_operands(spec, x2, dy2)[:2]
+    B2 = x2.shape[0]
+    splits = int(lib.uig_wgrad_pair2_splits(B, group, B2, g2, swap2, Mh, Mw, Np, Hq, Wq, Cq, spec.k, spec.k, spec.stride, spec.pad, _dt(x)))
+    ok = splits > 0 and tuple(x2.shape[1:]) == tuple(x.shape[1:]) and (layers2[0] is layers[swap2]) and (layers2[1] is layers[1 - swap2])
+    if ok:
+        per = splits * Np * spec.k * spec.k * Cq
+        ws = torch.empty((2 * per,), device=x.device, dtype=torch.float32)
+        L.check(lib.uig_wgrad_partial_pair2(_p(Pt), _p(Qt), _p(P2), _p(Q2), _p(ws), B, group, B2, g2, swap2, Mh, Mw, Np, Hq, Wq, Cq,
+                                            spec.k, spec.k, spec.stride, spec.pad, pm, splits, _dt(x), _stream()), "uig_wgrad_partial_pair2")
+        if _param_grads_pair(layers, spec, x, dy, group, colsum, [(ws[:per], splits), (ws[per:], splits)]):
+            return True
+    # could not combine after all: the stashed batch on its own, then the ordinary path for this one
+    pp = conv_wgrad_pair_partial(spec, x2, dy2, g2)
+    if not (pp and _param_grads_pair(layers2, spec, x2, dy2, g2, None, pp, bias=False)):
+        for i, l in enumerate(layers2):
+            xs, dys = (x2[:g2], dy2[:g2]) if i == 0 else (x2[g2:], dy2[g2:])
+            conv_wgrad(spec, xs, dys, out=l.weight.grad, accumulate=True)
+    return False
 
 
 class deferred_param_grads:
@@ -505,7 +583,7 @@ def _param_grads(layer, spec, x, dy, need_w, need_b, colsum=None, img0=0, partia
     return dW, db
 
 
-def _param_grads_pair(layers, spec, x, dy, group, colsum, pparts):
+def _param_grads_pair(layers, spec, x, dy, group, colsum, pparts, bias=True):
     """Both networks' dW (+ db) from a paired partial workspace in ONE reduce launch.  Only the training configuration
     (gradients accumulated in place into existing contiguous .grad buffers of both layers); returns False otherwise."""
     l1, l2 = layers
@@ -518,7 +596,7 @@ def _param_grads_pair(layers, spec, x, dy, group, colsum, pparts):
         return False
     k = spec.k
     _, _, _, _, Np, _, _, Cq, _, D0, D1 = _wgrad_operands(spec, x, dy)
-    rider = colsum is not None and colsum[2] == dy.shape[3]
+    rider = bias and colsum is not None and colsum[2] == dy.shape[3]
     lib = L.lib()
     if rider:
         cpart, spi, C = colsum
@@ -529,8 +607,9 @@ def _param_grads_pair(layers, spec, x, dy, group, colsum, pparts):
     else:
         L.check(lib.uig_wgrad_reduce_pair(_p(ws1), _p(l1.weight.grad), _p(l2.weight.grad), Np, Cq, k * k, splits, D0, D1, 1, None, None,
                                           0, 0, 0, 0, None, None, 0, _stream()), "uig_wgrad_reduce_pair")
-        for l, dys in ((l1, dy[:group]), (l2, dy[group:])):
-            bias_grad(dys, spec.cout, out=l.bias.grad, accumulate=True)
+        if bias:
+            for l, dys in ((l1, dy[:group]), (l2, dy[group:])):
+                bias_grad(dys, spec.cout, out=l.bias.grad, accumulate=True)
     return True
 
 
@@ -589,8 +668,19 @@ def _conv_backward(ctx, dy, layers, group):
         side = _side_stream(dy.device)
         side.wait_stream(main)
     with (torch.cuda.stream(side) if par else contextlib.nullcontext()):
-        pparts = conv_wgrad_pair_partial(spec, x, dy, group) if (npar == 2 and all(need_w) and PAIR_WGRAD) else None
-        if pparts and all(need_b) and _param_grads_pair(layers, spec, x, dy, group, colsum, pparts):
+        stash = _WG_STASH.get(torch.device(dy.device).index)
+        combined = stash is not None and npar == 2 and all(need_w) and all(need_b) and fused_all and PAIR_WGRAD and spec.kind == "conv" \
+            and _combined_wgrad(layers, spec, x, dy, group, colsum, stash)
+        pparts = None
+        if combined:
+            grads, layers_left = [None] * (2 * npar), ()
+            if par:      # a stashed batch is read by a later launch on the side stream
+                x.record_stream(side); dy.record_stream(side)
+        else:
+            pparts = conv_wgrad_pair_partial(spec, x, dy, group) if (npar == 2 and all(need_w) and PAIR_WGRAD) else None
+        if combined:
+            pass
+        elif pparts and all(need_b) and _param_grads_pair(layers, spec, x, dy, group, colsum, pparts):
             grads, layers_left = [None] * (2 * npar), ()
         else:
             layers_left = layers
