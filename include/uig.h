@@ -50,6 +50,8 @@ void uig_debug_set_strip(int on);
 /* tuning hook of the persistent strip kernel: dm = DMA issue placement (0 top of the K-step, 1 spread between MFMA groups),
  * grid = persistent grid size (0 = one block per CU) */
 void uig_debug_set_strip_pk(int dm, int grid);
+/* tuning / test hook: 1 (default) = uig_reflect3x3_dgrad_mirror_applicable may say 1; 0 = it never does (A/B against the border GEMM) */
+void uig_debug_set_mirror(int on);
 /* tuning / test hook: 1 (default) = 7x7 stride-1 convs with <= 16 output channels use the row-strip kernel */
 void uig_debug_set_rowstrip(int on);
 /* diagnostic build hook: device buffer (u64[blocks*8*4]) that receives in-kernel cycle stamps; NULL = off (default) */
@@ -115,6 +117,17 @@ int uig_conv_gather_bst(const void* x, const void* wp, const float* bias, const 
 int uig_reflect3x3_dgrad_border(const void* dy, const void* wp, const void* wp2, int group_images, void* bord,
                                 int B, int H, int W, int C, int Nrows, int ldc, int dtype, void* stream);
 int uig_conv_strip_applicable(int B, int H, int W, int Cin, int Nrows, int Ho, int Wo, int dh_min, int dh_max, int dtype);
+
+/* The same input gradient in ONE launch where the persistent strip kernel can fold the mirrored-border terms itself ("mirror
+ * pixels": sums of two - at the corners four - pixels of dy placed behind the tile's LDS strip and addressed by the taps that
+ * would have read a mirrored line or column; bf16, 64-pixel-wide maps of >= 8 lines, C % 64 == 0, Nrows == ldc, Nrows % 128 == 0):
+ * dx (B, H, W, ldc) = zero-padded transposed conv of dy (B, H, W, C) + mirrored terms [+ res_add of dx's shape].  No border
+ * buffer, no border GEMM in front.  uig_reflect3x3_dgrad_mirror_applicable: 1 where it applies, else use the two launches above.
+ * bst_* as uig_conv_gather_bst (all NULL / 0: none; needs res_add). */
+int uig_reflect3x3_dgrad_mirror_applicable(int B, int H, int W, int C, int Nrows, int ldc, int dtype);
+int uig_reflect3x3_dgrad_mirror(const void* dy, const void* wp, const void* wp2, int group_images, const void* res_add, void* dx,
+                                int B, int H, int W, int C, int Nrows, int ldc, int dtype,
+                                const void* bst_x, const float* bst_stats, int bst_act, float bst_slope, float* bst_partial, void* stream);
 
 /* ---- MX block-scaled fp8 path (BASELINE.json configs[4]): the 3x3 stride-1 pad-1 convolutions (forward: gather_mode direct,
  * zero or reflection padding; input gradient: gather_mode transposed, zero padding + border_add) on

@@ -12,6 +12,7 @@ ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--only", default="")
 ap.add_argument("--tile", type=int, default=0)
 ap.add_argument("--strip", type=int, default=1)
+ap.add_argument("--batch", type=int, default=8, help="images per launch (the fused step launches 16 = pass 1 and 8 = pass 2 at per-GPU batch 4)")
 args = ap.parse_args()
 dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 dev = "cuda"
@@ -67,21 +68,21 @@ def in_case(name, B, H, W, C, act, res):
     print(f"{name:34s} MB={nbytes/1e6:7.2f}  fwd {t_f:8.1f}us ({(2+ (1 if res else 0))*nbytes/t_f/1e6:6.2f} TB/s alg) | fwd+bwd {t_fb:8.1f}us", flush=True)
 
 
-B2 = 8   # the batch-2B launches of the fused step at per-GPU batch 4
-conv_case("res3x3 256->256 @64 B8", "conv", 256, 256, 3, 1, 1, "reflect", B2, 64, 64)
+B2 = args.batch
+conv_case("res3x3 256->256 @64", "conv", 256, 256, 3, 1, 1, "reflect", B2, 64, 64)
 conv_case("res3x3 256->256 @64 B4", "conv", 256, 256, 3, 1, 1, "reflect", 4, 64, 64)
-conv_case("down 64->128 s2 @256 B8", "conv", 64, 128, 3, 2, 1, "zero", B2, 256, 256)
-conv_case("down 128->256 s2 @128 B8", "conv", 128, 256, 3, 2, 1, "zero", B2, 128, 128)
-conv_case("up convT 256->128 @64 B8", "convT", 256, 128, 3, 2, 1, "zero", B2, 64, 64)
-conv_case("up convT 128->64 @128 B8", "convT", 128, 64, 3, 2, 1, "zero", B2, 128, 128)
-conv_case("stem 7x7 3->64 @256 B8", "conv", 3, 64, 7, 1, 3, "reflect", B2, 256, 256)
-conv_case("head 7x7 64->3 @256 B8", "conv", 64, 3, 7, 1, 3, "reflect", B2, 256, 256, act=L.ACT_TANH)
-conv_case("D1 4x4 3->64 s2 @256 B8", "conv", 3, 64, 4, 2, 1, "zero", B2, 256, 256, act=L.ACT_LRELU)
-conv_case("D2 4x4 64->128 s2 @128 B8", "conv", 64, 128, 4, 2, 1, "zero", B2, 128, 128)
-conv_case("D3 4x4 128->256 s2 @64 B8", "conv", 128, 256, 4, 2, 1, "zero", B2, 64, 64)
-conv_case("D4 4x4 256->512 s1 @32 B8", "conv", 256, 512, 4, 1, 1, "zero", B2, 32, 32)
-conv_case("D5 4x4 512->1 s1 @31 B8", "conv", 512, 1, 4, 1, 1, "zero", B2, 31, 31)
-in_case("IN+relu 256ch @64 B8", B2, 64, 64, 256, L.ACT_RELU, False)
-in_case("IN+res 256ch @64 B8", B2, 64, 64, 256, L.ACT_NONE, True)
-in_case("IN+relu 64ch @256 B8", B2, 256, 256, 64, L.ACT_RELU, False)
-in_case("IN+relu 128ch @128 B8", B2, 128, 128, 128, L.ACT_RELU, False)
+conv_case("down 64->128 s2 @256", "conv", 64, 128, 3, 2, 1, "zero", B2, 256, 256)
+conv_case("down 128->256 s2 @128", "conv", 128, 256, 3, 2, 1, "zero", B2, 128, 128)
+conv_case("up convT 256->128 @64", "convT", 256, 128, 3, 2, 1, "zero", B2, 64, 64)
+conv_case("up convT 128->64 @128", "convT", 128, 64, 3, 2, 1, "zero", B2, 128, 128)
+conv_case("stem 7x7 3->64 @256", "conv", 3, 64, 7, 1, 3, "reflect", B2, 256, 256)
+conv_case("head 7x7 64->3 @256", "conv", 64, 3, 7, 1, 3, "reflect", B2, 256, 256, act=L.ACT_TANH)
+conv_case("D1 4x4 3->64 s2 @256", "conv", 3, 64, 4, 2, 1, "zero", B2, 256, 256, act=L.ACT_LRELU)
+conv_case("D2 4x4 64->128 s2 @128", "conv", 64, 128, 4, 2, 1, "zero", B2, 128, 128)
+conv_case("D3 4x4 128->256 s2 @64", "conv", 128, 256, 4, 2, 1, "zero", B2, 64, 64)
+conv_case("D4 4x4 256->512 s1 @32", "conv", 256, 512, 4, 1, 1, "zero", B2, 32, 32)
+conv_case("D5 4x4 512->1 s1 @31", "conv", 512, 1, 4, 1, 1, "zero", B2, 31, 31)
+in_case("IN+relu 256ch @64", B2, 64, 64, 256, L.ACT_RELU, False)
+in_case("IN+res 256ch @64", B2, 64, 64, 256, L.ACT_NONE, True)
+in_case("IN+relu 64ch @256", B2, 256, 256, 64, L.ACT_RELU, False)
+in_case("IN+relu 128ch @128", B2, 128, 128, 128, L.ACT_RELU, False)

@@ -133,6 +133,58 @@ def test_reflect_dgrad_border_paths_agree(S, cin, cout, B, group, dtype):
     assert float((a.float() - b.float())[:, ring].abs().max()) <= tol
 
 
+@pytest.mark.parametrize("H,cin,cout,B,group,res", [(64, 256, 256, 8, 0, True), (64, 256, 256, 12, 4, False), (8, 128, 256, 96, 32, True),
+                                                    (12, 256, 64, 64, 0, True), (20, 128, 128, 40, 24, False)],
+                         ids=["bench-single", "bench-pair-uneven", "two-tile-map", "three-tile-map-1chunk", "five-tile-map"])
+def test_reflect_dgrad_mirror_pixels(H, cin, cout, B, group, res):
+    """Input gradient of a reflection-padded 3x3 conv with the mirrored terms folded INSIDE the persistent strip kernel (mirror
+    pixels, uig_reflect3x3_dgrad_mirror): maps of 2 tiles (top + bottom only), 3, 5 and 16 tiles per image, 1, 2 and 4 K-chunks
+    (the layer's cout = the gradient launch's reduction width), one and two weight sets, with and without the fused skip gradient;
+    against the CPU oracle (stock torch autograd of conv2d over F.pad(reflect), bf16-rounded operands), overall and on the ring of
+    pixels that receive mirrored terms (lines 1 / H-2, columns 1 / 62); and, on the square map, against the border-GEMM form."""
+    u, ops, networks = _mods()
+    lib, dt = u.lib.lib(), torch.bfloat16
+    W = 64
+    assert lib.uig_reflect3x3_dgrad_mirror_applicable(B, H, W, cout, cin, cin, u.lib.BF16) == 1
+    torch.manual_seed(300 + H)
+    g = group if group else B
+    ls = [networks.ConvLayer("conv", cin, cout, 3, 1, 1, "reflect", dtype=dt, device="cuda") for _ in range(2 if group else 1)]
+    ws = [torch.randn(cout, cin, 3, 3) * 0.05 for _ in ls]
+    for l, w in zip(ls, ws):
+        with torch.no_grad():
+            l.weight.copy_(w)
+        l.ensure_packed()
+    dy = torch.randn(B, cout, H, W) * 0.5
+    rs = torch.randn(B, cin, H, W) * 0.5 if res else None
+    xr = torch.zeros(B, cin, H, W, requires_grad=True)
+    parts = [(0, g, 0)] + ([(g, B, 1)] if group else [])
+    yref = torch.cat([F.conv2d(F.pad(xr[a:e], (1, 1, 1, 1), mode="reflect"), _bf(ws[i])) for a, e, i in parts])
+    yref.backward(_bf(dy))
+    dxref = xr.grad + (_bf(rs) if res else 0)
+    dyp = ops.to_nhwc(dy.cuda(), dt)
+    rsp = ops.to_nhwc(rs.cuda(), dt) if res else None
+    pair = (ls[1].wp_dgrad, None, g) if group else None
+    dx = ops.conv_dgrad(ls[0].spec, dyp, ls[0].wp_dgrad, (H, W), pair, res_add=rsp)
+    assert lib.uig_debug_last_conv_kernel() == u.lib.K_STRIP_PK
+    got = ops.from_nhwc(dx, cin).cpu()
+    tol = _tol(dt, dxref)
+    assert (got - dxref).abs().max() <= tol, f"L-inf {(got - dxref).abs().max()} of {dxref.abs().max()}"
+    ring = torch.zeros(H, W, dtype=torch.bool); ring[1] = ring[H - 2] = True; ring[:, 1] = ring[:, W - 2] = True
+    assert (got - dxref)[:, :, ring].abs().max() <= tol
+    # the mean error on the ring must look like the interior's (a missing or doubled mirrored term is O(1), not a rounding)
+    e_ring, e_in = float((got - dxref)[:, :, ring].abs().mean()), float((got - dxref)[:, :, ~ring].abs().mean())
+    assert e_ring <= 3 * e_in + 1e-6, (e_ring, e_in)
+    if H == W:
+        try:
+            lib.uig_debug_set_mirror(0)
+            assert lib.uig_reflect3x3_dgrad_mirror_applicable(B, H, W, cout, cin, cin, u.lib.BF16) == 0
+            old = ops.conv_dgrad(ls[0].spec, dyp, ls[0].wp_dgrad, (H, W), pair, res_add=rsp)
+        finally:
+            lib.uig_debug_set_mirror(1)
+        torch.cuda.synchronize()
+        assert float((dx.float() - old.float()).abs().max()) <= 1.6e-2 * float(old.float().abs().max())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("S", [16, 64, 20])
 def test_resblock_skip_gradient_fusion(S, dtype):

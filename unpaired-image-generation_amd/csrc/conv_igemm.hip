@@ -385,7 +385,7 @@ static int dispatch_igemm(const void* x, const void* wp, const float* bias, void
 int uig_try_conv_strip(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
                        float* in_partial, const void* border_add, const void* res_add, void* y, int B, int H, int W, int Cin, int Nrows,
                        int k, int pad_mode, const int* taps, int ntaps, int dh_min, int dh_max, int Ho, int Wo, int ldc, int Nstore,
-                       int act, float slope, int dtype, long x_bytes, long w_bytes, hipStream_t s, int* rc_out, const UigBst* bst);
+                       int act, float slope, int dtype, long x_bytes, long w_bytes, hipStream_t s, int* rc_out, const UigBst* bst, int mirror);
 
 int uig_try_conv_cin8(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
                       void* y, int B, int H, int W, int Cin, int Nrows, int pad_mode, const int* taps, int ntaps,
@@ -408,7 +408,7 @@ static int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b
 static int conv_gather_impl(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
                             float* in_partial, const void* border_add, const void* res_add, void* y, int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
                             int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
-                            int act, float slope, int dtype, void* stream, const UigBst* bst = nullptr) {
+                            int act, float slope, int dtype, void* stream, const UigBst* bst = nullptr, int mirror = 0) {
     UIG_CHECK_ARG(x && wp && y, "uig_conv_gather: null pointer");
     if (wp2 != nullptr) UIG_CHECK_ARG(group_images > 0 && group_images < B, "uig_conv_gather_pair: group_images=%d must be in (0, B=%d)", group_images, B);
     UIG_CHECK_ARG(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "uig_conv_gather: bad shape B=%d H=%d W=%d Ho=%d Wo=%d", B, H, W, Ho, Wo);
@@ -502,9 +502,10 @@ static int conv_gather_impl(const void* x, const void* wp, const float* bias, co
         int dmin = 127, dmax = -127, rc = 0;
         for (int t = 0; t < kH * kW; ++t) { const int dh = (d.tap[t] & 255) - 128; dmin = std::min(dmin, dh); dmax = std::max(dmax, dh); }
         if (uig_try_conv_strip(x, wp, bias, wp2, bias2, group_images, in_partial, border_add, res_add, y, B, H, W, Cin, Nrows, kH, pad_mode, d.tap, kH * kW, dmin, dmax,
-                               Ho, Wo, ldc, Nstore, act, slope, dtype, (long)d.x_bytes, (long)d.w_bytes, s, &rc, bst))
+                               Ho, Wo, ldc, Nstore, act, slope, dtype, (long)d.x_bytes, (long)d.w_bytes, s, &rc, bst, mirror))
             return rc;
     }
+    UIG_CHECK_ARG(mirror == 0, "uig_reflect3x3_dgrad_mirror: shape not taken by the persistent strip kernel (query uig_reflect3x3_dgrad_mirror_applicable)");
     UIG_CHECK_ARG(bst == nullptr, "uig_conv_gather_bst: the fused InstanceNorm-backward statistics need the bf16 strip kernel with border / residual terms");
     UIG_CHECK_ARG(border_add == nullptr && res_add == nullptr, "uig_conv_gather_ex: border_add / res_add need the stride-1 3x3 strip kernel (query uig_conv_strip_applicable)");
     if (wp2 != nullptr) {
@@ -565,6 +566,21 @@ extern "C" int uig_conv_gather_bst(const void* x, const void* wp, const float* b
     const UigBst b{bst_x, bst_stats, bst_partial, bst_act, bst_slope};
     return conv_gather_impl(x, wp, bias, wp2, bias2, wp2 ? group_images : 0, in_partial, border_add, res_add, y, B, H, W, Cin, Nrows, kH, kW, stride, pad,
                             pad_mode, gather_mode, Ho, Wo, ldc, Nstore, act, slope, dtype, stream, &b);
+}
+
+// Input gradient of a reflection-padded (pad 1) 3x3 stride-1 convolution in ONE launch: dx (B, H, W, ldc) = the zero-padded
+// transposed convolution of dy (B, H, W, C) with the mirrored-border terms folded inside the persistent strip kernel (mirror pixels,
+// conv_strip_pk.hip) [+ res_add, a tensor of dx's shape: the ResBlock skip gradient].  wp / wp2 + group_images as uig_conv_gather_pair
+// (the packed TRANSPOSED-gather operands).  Only where uig_reflect3x3_dgrad_mirror_applicable says 1.  bst_*: optional, as
+// uig_conv_gather_bst (all null / 0 = none).
+extern "C" int uig_reflect3x3_dgrad_mirror(const void* dy, const void* wp, const void* wp2, int group_images, const void* res_add, void* dx,
+                                           int B, int H, int W, int C, int Nrows, int ldc, int dtype,
+                                           const void* bst_x, const float* bst_stats, int bst_act, float bst_slope, float* bst_partial, void* stream) {
+    UIG_CHECK_ARG(dy && wp && dx, "uig_reflect3x3_dgrad_mirror: null pointer");
+    UIG_CHECK_ARG((bst_x != nullptr) == (bst_stats != nullptr) && (bst_x != nullptr) == (bst_partial != nullptr), "uig_reflect3x3_dgrad_mirror: bst_x, bst_stats and bst_partial go together");
+    const UigBst b{bst_x, bst_stats, bst_partial, bst_act, bst_slope};
+    return conv_gather_impl(dy, wp, nullptr, wp2, nullptr, wp2 ? group_images : 0, nullptr, nullptr, res_add, dx, B, H, W, C, Nrows, 3, 3, 1, 1, UIG_PAD_ZERO,
+                            UIG_GATHER_TRANSPOSED, H, W, ldc, ldc, UIG_ACT_NONE, 0.f, dtype, stream, bst_x ? &b : nullptr, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -27,6 +27,9 @@ struct StripDesc {
     const float* bst_stats;
     float* bst_partial;
     int bst_act; float bst_slope;
+    // persistent bf16 kernel only: 1 = this launch is the input gradient of a REFLECTION-padded 3x3 convolution on a 64-wide map and
+    // the kernel folds the mirrored-border terms itself (conv_strip_pk.hip, "mirror pixels"): no border_add buffer, no border GEMM
+    int mirror;
 };
 
 struct UigBst { const void* x; const float* stats; float* partial; int act; float slope; };
@@ -65,7 +68,7 @@ __device__ __forceinline__ void strip_init_acc(f32x4_t (&acc)[NT][MT], const flo
 // residual adds, optional InstanceNorm partial statistics; full-row stores through this wave's 64x64 LDS scratch when its 64
 // channels are all stored, else direct 8/16-byte stores.  The bias is already in the accumulators (strip_init_acc).
 // The caller has made sure (barrier) that `scratch` is free.
-template <typename T, int MT, int NT, int WM, int WN>
+template <typename T, int MT, int NT, int WM, int WN, bool BORD = true>
 __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], unsigned char* scratch, const StripDesc& d, T* __restrict__ y,
                                                int img, int p0, int wm, int wn, int n_base, int lane) {
     const int HoWo = d.Ho * d.Wo;
@@ -93,7 +96,7 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
                 // term (its line's or its column's) except the four pixels (1|S-2, 1|S-2) of an image, which also take the
                 // column and corner terms: those are loaded in the store loop by the lanes concerned (2 of 128 wave tiles of a
                 // 64x64 map).  2 prefetched chunks per row instead of 4: 64 registers instead of 128 at the epilogue's peak.
-                const bool hasb = d.border_add != nullptr, hasr = d.res_add != nullptr;
+                const bool hasb = BORD && d.border_add != nullptr, hasr = d.res_add != nullptr;      // !BORD: the caller never passes border_add
                 const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<void*>(hasb ? d.border_add : d.res_add), 0, hasb ? (unsigned)((long)d.B * 8 * S * d.ldc * (int)sizeof(T)) : 0u, 0x00020000);
                 const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(
@@ -109,19 +112,22 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
                 const bool bst = d.bst_partial != nullptr && pw < HoWo;                 // wave-uniform
                 const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<void*>(bst ? d.bst_x : (hasr ? d.res_add : d.border_add)), 0, bst ? (unsigned)((long)d.B * HoWo * d.ldc * (int)sizeof(T)) : 0u, 0x00020000);
-                u32x4_t pre[ND][2], prex[ND];                          // border term (line or column), residual tensor; the norm's input
+                u32x4_t pre[ND][BORD ? 2 : 1], prex[ND];               // [border term (line or column),] residual tensor; the norm's input
+                constexpr int PR = BORD ? 1 : 0;                       // slot of the residual chunk
                 unsigned both = 0;                                     // bit i: row i is one of the image's four double-border pixels
                 auto fetch = [&](int i) {                              // row i -> slot i % ND (static after unrolling)
                     const int p = pw + r0 + 8 * i;
                     const int h = p / d.Wo, w = p - h * d.Wo;
                     const bool ok = p < HoWo;
-                    const bool okb = ok & hasb;
-                    const bool rt_ = okb & (h == 1), rb_ = okb & (h == S - 2), cl_ = okb & (w == 1), cr_ = okb & (w == S - 2);
-                    const int o0 = (rt_ | rb_) ? boff(rt_ ? 0 : 1, w) : ((cl_ | cr_) ? boff(cl_ ? 2 : 3, h) : -1);
-                    pre[i % ND][0] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsb, o0, 0, 0));
-                    pre[i % ND][1] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                    if constexpr (BORD) {
+                        const bool okb = ok & hasb;
+                        const bool rt_ = okb & (h == 1), rb_ = okb & (h == S - 2), cl_ = okb & (w == 1), cr_ = okb & (w == S - 2);
+                        const int o0 = (rt_ | rb_) ? boff(rt_ ? 0 : 1, w) : ((cl_ | cr_) ? boff(cl_ ? 2 : 3, h) : -1);
+                        pre[i % ND][0] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsb, o0, 0, 0));
+                        both |= (((rt_ | rb_) & (cl_ | cr_)) ? 1u : 0u) << i;
+                    }
+                    pre[i % ND][PR] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
                         rsr, ok ? (int)((((long)img * HoWo + p) * d.ldc + nw0 + c * E) * (long)sizeof(T)) : -1, 0, 0));
-                    both |= (((rt_ | rb_) & (cl_ | cr_)) ? 1u : 0u) << i;
                 };
                 auto fetch_x = [&](int i) {
                     const int p = pw + r0 + 8 * i;
@@ -148,12 +154,12 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
                     float f[E], g[E];
                     chunk_to_f32<T>(v, f);
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) {
+                    for (int k = 0; k < (BORD ? 2 : 1); ++k) {
                         chunk_to_f32<T>(pre[i % ND][k], g);
 #pragma unroll
                         for (int e = 0; e < E; ++e) f[e] += g[e];
                     }
-                    if ((both >> i) & 1u) {                            // rare: column term + corner term of a double-border pixel
+                    if (BORD && ((both >> i) & 1u)) {                  // rare: column term + corner term of a double-border pixel
                         const int p = pw + r;
                         const int h = p / d.Wo, w = p - h * d.Wo;
                         const u32x4_t cv = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsb, boff(w == 1 ? 2 : 3, h), 0, 0));

@@ -23,7 +23,22 @@
 // SWZ: strip swizzle (1 = rotation, 0 = the XOR of conv_igemm.hip); LGK: wait for this wave's own fragment reads before the
 // K-step barrier (strictly orders them before the DMA that overwrites the weight stage; 0 = rely on the DMA's latency as the
 // one-tile-per-block kernel does); STAMP: diagnostic build writing s_memtime stamps per wave to d.dbg
-template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false>
+//
+// MIRROR (bf16, 64-pixel-wide maps): input gradient of a REFLECTION-padded 3x3 convolution without a border GEMM.  The adjoint of
+// pad-1 reflection folds padded line -1 onto line 1 and line H onto line H-2 (columns alike), i.e.
+//     dx[i][j] = sum_{dh,dw} S_{dh,dw}[i+dh][j+dw] * W'[dh][dw],     S_{dh,dw} = dy except:
+//     dh = +1: line 2 := line 2 + line 0      dh = -1: line H-3 := line H-3 + line H-1      (and the same in columns with dw)
+// - a ZERO-padded input gradient whose taps read a few "mirror pixels" (sums of two, at the four corners of four, pixels of dy)
+// in place of the pixel itself: output line 1 with dh = +1, line H-2 with dh = -1, column 1 with dw = +1, column W-2 with dw = -1.
+// The row table addresses pixels individually, so the mirror pixels are just extra strip slots behind the tile's NS pixels:
+//     NS + r, NS + 6 + r           column mirrors of strip line r: dy[r][2] + dy[r][0], dy[r][W-3] + dy[r][W-1]       (r < 6)
+//     NS + 12 + c  (c < 64)        line mirror (tile 0: dy[2][c] + dy[0][c]; last tile: dy[H-3][c] + dy[H-1][c])
+//     NS + 12 + 64, NS + 12 + 65   the line mirror's own column mirrors (four-pixel sums: the corner terms)
+// summed in fp32 from the landed strip and rounded once to bf16, by all threads during the LAST tap-step of the previous chunk
+// (every strip piece of the chunk has landed and been published by then: pieces are issued in steps 0-6), visible to all after
+// the next step's barrier.  12 (+66) pixels x 8 chunks of work per K chunk against 36 x 512 MFMAs: nothing, and the 22-us
+// eight-phase border GEMM in front of every input-gradient launch (uig_reflect3x3_dgrad_border) and the epilogue's border loads go.
+template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false, bool MIRROR = false>
 __global__ __launch_bounds__(512, 2)
 void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, const float* __restrict__ bias1, T* __restrict__ y,
                           const StripDesc d) {
@@ -37,6 +52,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
     constexpr int ZW = CAP * 128 / SCRW;          // the wave whose scratch covers the region's zero row
     static_assert(CAP % 8 == 0 && PIECES <= NTAPS * NW, "one strip piece per wave per K-step");
     static_assert(!XPREF || (CAP * 128) % SCRW + 1024 <= SCRW, "zero row must lie inside one wave's scratch");
+    static_assert(!MIRROR || (sizeof(T) == 2 && SWZ == 1 && XPREF && 6 * 64 + 12 <= CAP && 5 * 64 + 12 + 66 <= CAP), "mirror pixels: bf16, 64-wide maps");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
 
@@ -112,6 +128,50 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
         issue_w1(0, t.g2, so, region); issue_w1(1, t.g2, so, region);
     };
 
+    // ---- mirror pixels of one strip chunk (MIRROR): see the kernel comment.  Block-uniform control flow, no barrier inside.
+    auto mirror_fix = [&](int region, const Tile& t) {
+        if constexpr (MIRROR) {
+            unsigned char* sb = smem + region * REG;
+            const int nrows = t.NS >> 6;
+            const bool top = t.ti == 0, edge = top || t.ti == tpi - 1;
+            const int rA = (top ? 2 : d.H - 3) - t.lo, rB = (top ? 0 : d.H - 1) - t.lo;      // strip lines summed into the line mirror
+            const int nitem = (edge ? 12 + 66 : 12) * 8;
+            auto ld = [&](int slot, int k, float (&f)[8]) {
+                chunk_to_f32<T>(*reinterpret_cast<const u32x4_t*>(sb + slot * 128 + (((k + (slot & 6)) & 7) << 4)), f);
+            };
+            for (int i = tid; i < nitem; i += 64 * NW) {
+                const int px = i >> 3, k = i & 7;
+                int s0, s1, s2 = -1, s3 = -1;
+                if (px < 12) {
+                    const int side = px >= 6 ? 1 : 0, r = px - 6 * side;
+                    if (r >= nrows) continue;
+                    s0 = r * 64 + (side ? d.W - 3 : 2); s1 = r * 64 + (side ? d.W - 1 : 0);
+                } else {
+                    const int c = px - 12;
+                    if (c < 64) { s0 = rA * 64 + c; s1 = rB * 64 + c; }
+                    else {
+                        const int ca = c == 64 ? 2 : d.W - 3, cb = c == 64 ? 0 : d.W - 1;
+                        s0 = rA * 64 + ca; s1 = rB * 64 + ca; s2 = rA * 64 + cb; s3 = rB * 64 + cb;
+                    }
+                }
+                float f[8], g[8];
+                ld(s0, k, f); ld(s1, k, g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += g[e];
+                if (s2 >= 0) {
+                    ld(s2, k, g);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += g[e];
+                    ld(s3, k, g);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += g[e];
+                }
+                const int so = t.NS + px;
+                *reinterpret_cast<u32x4_t*>(sb + so * 128 + (((k + (so & 6)) & 7) << 4)) = f32_to_chunk<T>(f);
+            }
+        }
+    };
+
     unsigned long long tstamp[8];
     int nst = 0;
     auto stamp = [&]() {
@@ -160,7 +220,16 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) {
                 const int s0 = hrow[t / 3] + wcol[t % 3];
-                const int s = (pv & (s0 >= 0)) ? s0 : CAP;
+                int s = (pv & (s0 >= 0)) ? s0 : CAP;
+                if constexpr (MIRROR) {                                         // taps that read a mirror pixel instead (kernel comment)
+                    const int dh = (d.tap[3 * (t / 3)] & 255) - 128, dw = ((d.tap[t % 3] >> 8) & 255) - 128;
+                    const bool ra = (ho == 1 && dh == 1) || (ho == d.H - 2 && dh == -1);
+                    const bool cl = wo == 1 && dw == 1, cr = wo == d.W - 2 && dw == -1;
+                    if (s != CAP) {
+                        if (ra) s = tl.NS + 12 + (cl ? 64 : (cr ? 65 : wo + dw));
+                        else if (cl | cr) s = tl.NS + (cr ? 6 : 0) + (ho + dh - tl.lo);
+                    }
+                }
                 rt[t][b] = (unsigned short)(s * 128 + ((SWZ ? ((q + (s & 6)) & 7) : (q ^ ((s >> 1) & 7))) << 4));
             }
         }
@@ -171,6 +240,13 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
     for (int r = 0;; ++r) {
         const Tile nxt = get_tile(r + 1);
         if (cur.ti != rt_ti) { build_rt(cur); rt_ti = cur.ti; }
+        if constexpr (MIRROR) {
+            if (r == 0) {                                       // the block's first chunk: nothing ran in front of it to hide this behind
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                mirror_fix(0, cur);
+            }
+        }
         const float* bias = cur.g2 ? d.bias2 : bias1;
 
         f32x4_t acc[NT][MT];
@@ -249,6 +325,11 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                     if constexpr (DM == 4) __builtin_amdgcn_s_setprio(0);
                 }
                 }
+                if constexpr (MIRROR) {
+                    // last step of the chunk: the next chunk's strip (issued in steps 0-6) is complete and published; its mirror
+                    // pixels are published by the next step's barrier
+                    if (last_t && s_on) mirror_fix(pc ^ 1, last_cc ? nxt : cur);
+                }
             }
         }
         stamp();                                               // 2 / 5: K loop done
@@ -263,7 +344,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
         // spilled to scratch, reloaded one `s_waitcnt vmcnt(0)` at a time behind the epilogue's own global stores).
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
-        strip_epilogue<T, MT, NT, WM, WN>(acc, scratch, d, y, cur.img, cur.p0, wm, wn, cur.n_base, lane_e);
+        strip_epilogue<T, MT, NT, WM, WN, !MIRROR>(acc, scratch, d, y, cur.img, cur.p0, wm, wn, cur.n_base, lane_e);
         stamp();                                               // 3 / 6: epilogue issued
         if (!nxt.valid) break;
         if constexpr (XPREF) {
@@ -303,10 +384,10 @@ static int device_cus() {
     return n;
 }
 
-template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false>
+template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false, bool MIRROR = false>
 static int launch_pk(const void* x, const void* wp, const float* bias, void* y, const StripDesc& d, int ntiles, hipStream_t s) {
     const size_t smem = 2 * ((size_t)(CAP + 8) * 128 + 128 * 128);
-    auto kern = conv_strip_pk_kernel<T, CAP, DM, SWZ, LGK, STAMP>;
+    auto kern = conv_strip_pk_kernel<T, CAP, DM, SWZ, LGK, STAMP, MIRROR>;
     static SmemAttrOnce attr_once;
     {
         hipError_t e = attr_once.ensure(reinterpret_cast<const void*>(kern), smem);
@@ -332,6 +413,7 @@ int uig_launch_strip_pk(const void* x, const void* wp, const float* bias, void* 
     const int tpi = (d.Ho * d.Wo + 255) / 256;
     const int ntiles = d.B * tpi * (d.Nrows / 128);
     if (dtype == UIG_BF16) {
+        if (d.mirror) return launch_pk<bf16_t, 448, 0, 1, true, false, true>(x, wp, bias, y, d, ntiles, s);
         if (d.dbg != nullptr) return launch_pk<bf16_t, 448, 0, 1, true, true>(x, wp, bias, y, d, ntiles, s);
         switch (g_pk_dm) {      // tuning variants (A/B in one process: scripts/bench_strip_pk.py)
             case 2: return launch_pk<bf16_t, 448, 0, 0, true>(x, wp, bias, y, d, ntiles, s);      // XOR swizzle (for the bank-conflict counters)
@@ -342,5 +424,22 @@ int uig_launch_strip_pk(const void* x, const void* wp, const float* bias, void* 
             default: return launch_pk<bf16_t, 448, 0, 1, true>(x, wp, bias, y, d, ntiles, s);
         }
     }
+    if (d.mirror) return uig_set_error(-1, "conv_strip_pk: mirror pixels are a bf16 path");
     return launch_pk<float, 448, 0>(x, wp, bias, y, d, ntiles, s);
+}
+
+// 1 if a launch that uig_strip_pk_ok accepts can also fold the mirrored-border terms of a reflection-padded convolution's input
+// gradient in the kernel (StripDesc::mirror): bf16, zero-padded transposed gather on a 64-pixel-wide map of >= 8 lines in whole
+// 4-line tiles, taps at (-1, 0, +1)^2, all channels stored, no border buffer.
+bool uig_strip_pk_mirror_ok(const StripDesc& d, int dtype) {
+    if (dtype != UIG_BF16 || d.pad_mode != UIG_PAD_ZERO || d.W != 64 || d.Wo != 64 || d.H != d.Ho || d.H < 8 || d.H % 4 != 0) return false;
+    if (d.border_add != nullptr || d.Nstore != d.Nrows || d.dh_min != -1 || d.dh_max != 1) return false;
+    bool seen[3][3] = {};
+    for (int t = 0; t < 9; ++t) {
+        const int dh = (d.tap[t] & 255) - 128, dw = ((d.tap[t] >> 8) & 255) - 128;
+        if (dh < -1 || dh > 1 || dw < -1 || dw > 1) return false;
+        seen[dh + 1][dw + 1] = true;
+    }
+    for (auto& r : seen) for (bool b : r) if (!b) return false;
+    return true;
 }

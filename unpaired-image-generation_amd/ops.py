@@ -423,8 +423,13 @@ def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, 
     B, Ho, Wo, Cd = dy.shape
     H, W = in_hw
     s = _stream()
+    # pad-1 reflection 3x3 on 64-wide bf16 maps (the ResBlock convs at 256x256): the persistent strip kernel folds the mirrored
+    # terms itself (mirror pixels, uig_reflect3x3_dgrad_mirror) - one launch, square map or not
+    mirror = (spec.kind == "conv" and spec.reflect and spec.k == 3 and spec.pad == 1 and spec.stride == 1 and REFLECT_DGRAD_DIRECT
+              and mx is None and spec.cin_p == spec.cin
+              and L.lib().uig_reflect3x3_dgrad_mirror_applicable(B, Ho, Wo, Cd, spec.cin, spec.cin_p, _dt(dy)) == 1)
     if res_add is not None:
-        fusable = (spec.kind == "conv" and spec.reflect and spec.k == 3 and spec.pad == 1 and spec.stride == 1 and H == W and 4 <= H <= 128
+        fusable = (spec.kind == "conv" and spec.reflect and spec.k == 3 and spec.pad == 1 and spec.stride == 1 and ((H == W and 4 <= H <= 128) or mirror)
                    and REFLECT_DGRAD_DIRECT and FUSE_SKIP_GRAD and res_add.is_contiguous() and res_add.dtype == dy.dtype
                    and tuple(res_add.shape) == (B, H, W, spec.cin_p)
                    and L.lib().uig_conv_strip_applicable(B, Ho, Wo, Cd, spec.cin, H, W, -1, 1, _dt(dy)) == 1)
@@ -436,17 +441,19 @@ def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, 
         _gather(dy, wp_dgrad, None, dx, B, Ho, Wo, Cd, spec.cin, spec, spec.stride, spec.pad, L.PAD_ZERO, L.GATHER_DIRECT, H, W,
                 spec.cin_p, L.ACT_NONE, 0.0, "uig_conv_gather(convT dgrad)", pair)
         return dx
-    if spec.reflect and spec.k == 3 and spec.pad == 1 and spec.stride == 1 and H == W and 4 <= H <= 128 and REFLECT_DGRAD_DIRECT \
-            and L.lib().uig_conv_strip_applicable(B, Ho, Wo, Cd, spec.cin, H, W, -1, 1, _dt(dy)) == 1:
+    if mirror or (spec.reflect and spec.k == 3 and spec.pad == 1 and spec.stride == 1 and H == W and 4 <= H <= 128 and REFLECT_DGRAD_DIRECT
+                  and L.lib().uig_conv_strip_applicable(B, Ho, Wo, Cd, spec.cin, H, W, -1, 1, _dt(dy)) == 1):
         # pad-1 reflection, 3x3: dx on the exact H x W grid (zero-pad transposed conv: whole tile rounds on 256 CUs) plus the
         # mirrored-border terms from one small 8-phase GEMM, added in the strip kernel's epilogue.  No (H+2)x(W+2)
         # padded gradient, no fold kernel.
         lib = L.lib()
-        bord = torch.empty((B, 8, H, spec.cin_p), device=dy.device, dtype=dy.dtype)
         wp2, g = (pair[0], pair[2]) if pair is not None else (None, 0)
-        L.check(lib.uig_reflect3x3_dgrad_border(_p(dy), _p(wp_dgrad), _p(wp2), g, _p(bord), B, Ho, Wo, Cd, spec.cin, spec.cin_p,
-                                                _dt(dy), s), "uig_reflect3x3_dgrad_border")
         dx = torch.empty((B, H, W, spec.cin_p), device=dy.device, dtype=dy.dtype)
+        bord = None
+        if not mirror:
+            bord = torch.empty((B, 8, H, spec.cin_p), device=dy.device, dtype=dy.dtype)
+            L.check(lib.uig_reflect3x3_dgrad_border(_p(dy), _p(wp_dgrad), _p(wp2), g, _p(bord), B, Ho, Wo, Cd, spec.cin, spec.cin_p,
+                                                    _dt(dy), s), "uig_reflect3x3_dgrad_border")
         bpart = None
         if bst is not None and FUSE_BWD_STATS and dy.dtype == torch.bfloat16 and (H * W) % 64 == 0 and spec.cin % 64 == 0 and spec.cin_p == spec.cin \
                 and tuple(bst[0].shape) == (B, H, W, spec.cin_p) and bst[0].dtype == dy.dtype and bst[0].is_contiguous():
@@ -458,6 +465,12 @@ def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, 
             dq, ds = _mx_operand(dy)
             _conv3x3_mx(dq, ds, mx, None, None, pair[2] if pair is not None else 0, dx, spec.cin, L.PAD_ZERO, L.GATHER_TRANSPOSED,
                         L.ACT_NONE, 0.0, None, bord, res_add, bst)
+        elif mirror:
+            if bst is not None and res_add is None:
+                bst, bpart = None, None
+            b5 = (_p(bst[0]), _p(bst[1]), bst[2], bst[3], _p(bst[4])) if bst is not None else (None, None, 0, 0.0, None)
+            L.check(lib.uig_reflect3x3_dgrad_mirror(_p(dy), _p(wp_dgrad), _p(wp2), g, _p(res_add), _p(dx), B, Ho, Wo, Cd, spec.cin, spec.cin_p,
+                                                    _dt(dy), *b5, s), "uig_reflect3x3_dgrad_mirror")
         else:
             _gather(dy, wp_dgrad, None, dx, B, Ho, Wo, Cd, spec.cin, spec, 1, 1, L.PAD_ZERO, L.GATHER_TRANSPOSED, H, W, spec.cin_p,
                     L.ACT_NONE, 0.0, "uig_conv_gather(dgrad+border)", pair, None, bord, res_add, bst)
