@@ -209,6 +209,12 @@ int uig_wgrad_reduce_pair(const float* workspace, float* dW_a, float* dW_b, int 
                           int D0, int D1, int accumulate, const float* colsum_a, const float* colsum_b,
                           int nslab_a, int nslab_b, int C, int Nreal, float* db_a, float* db_b, int accumulate_db,
                           void* stream);
+/* The same with TWO runs of column-sum slabs per network in the bias riders (the reduce behind uig_wgrad_partial_pair2, whose
+ * partials cover both generator passes): db_x (+)= sum of colsum_x's nslab_x slabs + sum of colsum_x2's nslab_x2 slabs. */
+int uig_wgrad_reduce_pair2(const float* workspace, float* dW_a, float* dW_b, int Np, int Cq, int taps, int splits,
+                           int D0, int D1, int accumulate, const float* colsum_a, const float* colsum_b, int nslab_a, int nslab_b,
+                           const float* colsum_a2, const float* colsum_b2, int nslab_a2, int nslab_b2,
+                           int C, int Nreal, float* db_a, float* db_b, int accumulate_db, void* stream);
 int uig_wgrad_reduce(const float* workspace, float* dW, int Np, int Cq, int taps, int splits,
                      int D0, int D1, int accumulate, void* stream);
 /* uig_wgrad_reduce + the layer's bias gradient from the InstanceNorm backward's column-sum partials, in one launch */

@@ -243,12 +243,14 @@ __global__ __launch_bounds__((BN >= 256 ? 512 : 256), 2) void wgrad_kernel(const
 
 // Optional rider on the reduce launch: the bias gradient from the InstanceNorm backward's column-sum partials
 // (partial[slab][C][2], see instnorm.hip) - saves one tiny launch per layer on the backward's side stream.
-struct BiasRider { const float* cpart; float* db; int nslab, C, nreal, accumulate, main_blocks; };
+struct BiasRider { const float* cpart; float* db; int nslab, C, nreal, accumulate, main_blocks; const float* cpart2; int nslab2; };      // cpart2: optional second run of slabs (the other generator pass's)
 __device__ __forceinline__ void bias_rider_block(const BiasRider& br, int blk) {
     const int sl = threadIdx.x & 15, c = blk * 16 + (threadIdx.x >> 4);
     double a = 0.0;
     if (c < br.C)
         for (int s = sl; s < br.nslab; s += 16) a += (double)br.cpart[((long)s * br.C + c) * 2];
+    if (c < br.C && br.cpart2 != nullptr)
+        for (int s = sl; s < br.nslab2; s += 16) a += (double)br.cpart2[((long)s * br.C + c) * 2];
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 16);
     if (sl == 0 && c < br.nreal) br.db[c] = br.accumulate ? br.db[c] + (float)a : (float)a;
@@ -477,7 +479,7 @@ extern "C" int uig_wgrad_partial_pair2(const void* P, const void* Q, const void*
 }
 
 static int wgrad_reduce_impl(const float* workspace, float* dW, int Np, int Cq, int taps, int splits, int D0, int D1, int accumulate,
-                             BiasRider br, void* stream, float* dW2 = nullptr, BiasRider br2 = BiasRider{nullptr, nullptr, 0, 0, 0, 0, 0}) {
+                             BiasRider br, void* stream, float* dW2 = nullptr, BiasRider br2 = BiasRider{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0}) {
     UIG_CHECK_ARG(workspace && dW, "uig_wgrad_reduce: null pointer");
     UIG_CHECK_ARG(D0 <= Np && D1 <= Cq && D0 > 0 && D1 > 0 && taps > 0 && splits > 0, "uig_wgrad_reduce: bad dims");
     const long total = (long)D0 * D1;
@@ -510,15 +512,28 @@ extern "C" int uig_wgrad_reduce_pair(const float* workspace, float* dW_a, float*
     BiasRider ra{nullptr, nullptr, 0, 0, 0, 0, 0}, rb = ra;
     if (colsum_a != nullptr) {
         UIG_CHECK_ARG(db_a && db_b && nslab_a > 0 && nslab_b > 0 && Nreal > 0 && Nreal <= C, "uig_wgrad_reduce_pair: bad bias args");
-        ra = BiasRider{colsum_a, db_a, nslab_a, C, Nreal, accumulate_db, 0};
-        rb = BiasRider{colsum_b, db_b, nslab_b, C, Nreal, accumulate_db, 0};
+        ra = BiasRider{colsum_a, db_a, nslab_a, C, Nreal, accumulate_db, 0, nullptr, 0};
+        rb = BiasRider{colsum_b, db_b, nslab_b, C, Nreal, accumulate_db, 0, nullptr, 0};
     }
+    return wgrad_reduce_impl(workspace, dW_a, Np, Cq, taps, splits, D0, D1, accumulate, ra, stream, dW_b, rb);
+}
+
+// uig_wgrad_reduce_pair whose bias riders sum TWO runs of column-sum slabs per network (the two generator passes whose weight
+// gradients uig_wgrad_partial_pair2 reduced together): db_x (+)= sum colsum_x[0..nslab_x) + sum colsum_x2[0..nslab_x2).
+extern "C" int uig_wgrad_reduce_pair2(const float* workspace, float* dW_a, float* dW_b, int Np, int Cq, int taps, int splits,
+                                      int D0, int D1, int accumulate, const float* colsum_a, const float* colsum_b, int nslab_a, int nslab_b,
+                                      const float* colsum_a2, const float* colsum_b2, int nslab_a2, int nslab_b2,
+                                      int C, int Nreal, float* db_a, float* db_b, int accumulate_db, void* stream) {
+    UIG_CHECK_ARG(dW_a && dW_b && colsum_a && colsum_b && colsum_a2 && colsum_b2 && db_a && db_b, "uig_wgrad_reduce_pair2: null pointer");
+    UIG_CHECK_ARG(nslab_a > 0 && nslab_b > 0 && nslab_a2 > 0 && nslab_b2 > 0 && Nreal > 0 && Nreal <= C, "uig_wgrad_reduce_pair2: bad bias args");
+    const BiasRider ra{colsum_a, db_a, nslab_a, C, Nreal, accumulate_db, 0, colsum_a2, nslab_a2};
+    const BiasRider rb{colsum_b, db_b, nslab_b, C, Nreal, accumulate_db, 0, colsum_b2, nslab_b2};
     return wgrad_reduce_impl(workspace, dW_a, Np, Cq, taps, splits, D0, D1, accumulate, ra, stream, dW_b, rb);
 }
 
 extern "C" int uig_wgrad_reduce(const float* workspace, float* dW, int Np, int Cq, int taps, int splits,
                                 int D0, int D1, int accumulate, void* stream) {
-    return wgrad_reduce_impl(workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate, BiasRider{nullptr, nullptr, 0, 0, 0, 0, 0}, stream);
+    return wgrad_reduce_impl(workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate, BiasRider{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0}, stream);
 }
 
 // the same launch also finishes the layer's bias gradient from column-sum partials (uig_instnorm_act_bwd_colsum)
@@ -527,5 +542,5 @@ extern "C" int uig_wgrad_reduce_bias(const float* workspace, float* dW, int Np, 
                                      int Nreal, float* db, int accumulate_db, void* stream) {
     UIG_CHECK_ARG(colsum_partial && db && nslab_total > 0 && Nreal > 0 && Nreal <= C, "uig_wgrad_reduce_bias: bad bias args");
     return wgrad_reduce_impl(workspace, dW, Np, Cq, taps, splits, D0, D1, accumulate,
-                             BiasRider{colsum_partial, db, nslab_total, C, Nreal, accumulate_db, 0}, stream);
+                             BiasRider{colsum_partial, db, nslab_total, C, Nreal, accumulate_db, 0, nullptr, 0}, stream);
 }

@@ -63,6 +63,7 @@ SIGNATURES = {
     "uig_wgrad_pair2_splits": (_i, [_i] * 16),
     "uig_wgrad_partial_pair2": (_i, [_vp] * 5 + [_i] * 18 + [_vp]),
     "uig_wgrad_reduce_pair": (_i, [_vp, _vp, _vp] + [_i] * 7 + [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "uig_wgrad_reduce_pair2": (_i, [_vp] * 3 + [_i] * 7 + [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "uig_wgrad_reduce": (_i, [_vp, _vp] + [_i] * 7 + [_vp]),
     "uig_wgrad_reduce_bias": (_i, [_vp, _vp] + [_i] * 7 + [_vp, _i, _i, _i, _vp, _i, _vp]),
     "uig_colsum_workspace_floats": (_sz, [_i]),

@@ -49,7 +49,7 @@ def release_side_streams(device) -> None:
 class combined_pass_wgrad:
     """Region (the generator phase's backward pass) in which a layer pair that is back-propagated TWICE - the step's two generator
     passes run the same two weight sets, the second pass's backward first - gets ONE weight-gradient launch for both batches:
-    the first visit stashes its (x, dy) and only settles the bias gradient, the second visit runs uig_wgrad_partial_pair2 over
+    the first visit only stashes its (x, dy, column-sum partials for the bias gradient), the second visit runs uig_wgrad_partial_pair2 over
     both batches and the usual paired reduce.  The fixed cost of a split-K launch (fill / drain, partial slabs, reduce) is paid
     once per layer instead of twice: 147 us against 111 + 74 us per ResBlock conv pair at batch 4 (scripts/bench_wgrad_combine.py).
     Anything still stashed on exit (a pair visited once) is flushed with an ordinary launch."""
@@ -71,12 +71,8 @@ class combined_pass_wgrad:
             main = torch.cuda.current_stream(self.idx)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                for x, dy, group, layers in st.values():
-                    pp = conv_wgrad_pair_partial(layers[0].spec, x, dy, group)
-                    if not (pp and _param_grads_pair(layers, layers[0].spec, x, dy, group, None, pp, bias=False)):
-                        for i, l in enumerate(layers):
-                            xs, dys = (x[:group], dy[:group]) if i == 0 else (x[group:], dy[group:])
-                            conv_wgrad(l.spec, xs, dys, out=l.weight.grad, accumulate=True)
+                for x, dy, group, layers, cs in st.values():
+                    _stashed_alone(x, dy, group, layers, cs)
             main.wait_stream(side)
         return False
 
@@ -91,16 +87,15 @@ def _combined_wgrad(layers, spec, x, dy, group, colsum, stash):
     if prev is None:
         if int(lib.uig_wgrad_pair2_splits(B, group, B, group, 0, Mh, Mw, Np, Hq, Wq, Cq, spec.k, spec.k, spec.stride, spec.pad, _dt(x))) <= 0:
             return False
-        # first visit (the later pass): the bias gradient now, the weight gradient together with the other pass's batch
-        for i, l in enumerate(layers):
-            dys, i0 = (dy[:group], 0) if i == 0 else (dy[group:], group)
-            if colsum is not None and colsum[2] == dy.shape[3]:
-                _bias_grad_from_partials(colsum, i0, dys.shape[0], spec.cout, l.bias.grad, True)
-            else:
-                bias_grad(dys, spec.cout, out=l.bias.grad, accumulate=True)
-        stash[key] = (x, dy, group, layers)
+        # first visit (the later pass): weight AND bias gradient together with the other pass's batch (its column-sum partials
+        # travel with the stash and ride on the combined reduce); no partials -> the bias gradient now
+        cs = colsum if (colsum is not None and colsum[2] == dy.shape[3]) else None
+        if cs is None:
+            for i, l in enumerate(layers):
+                bias_grad(dy[:group] if i == 0 else dy[group:], spec.cout, out=l.bias.grad, accumulate=True)
+        stash[key] = (x, dy, group, layers, cs)
         return True
-    x2, dy2, g2, layers2 = prev
+    x2, dy2, g2, layers2, cs2 = prev
     swap2 = 1 if layers2[0] is layers[1] else 0
     P2, Q2 = _wgrad_operands(spec, x2, dy2)[:2]
     B2 = x2.shape[0]
@@ -111,15 +106,31 @@ def _combined_wgrad(layers, spec, x, dy, group, colsum, stash):
         ws = torch.empty((2 * per,), device=x.device, dtype=torch.float32)
         L.check(lib.uig_wgrad_partial_pair2(_p(Pt), _p(Qt), _p(P2), _p(Q2), _p(ws), B, group, B2, g2, swap2, Mh, Mw, Np, Hq, Wq, Cq,
                                             spec.k, spec.k, spec.stride, spec.pad, pm, splits, _dt(x), _stream()), "uig_wgrad_partial_pair2")
-        if _param_grads_pair(layers, spec, x, dy, group, colsum, [(ws[:per], splits), (ws[per:], splits)]):
+        c2 = None
+        if cs2 is not None:      # images of network a (= layers[0]) / b in the stashed batch
+            c2 = (cs2, (g2, B2 - g2), (0, g2)) if swap2 else (cs2, (0, g2), (g2, B2 - g2))
+            if not (colsum is not None and colsum[2] == dy.shape[3]):      # no rider on this pass to carry them
+                for (i0, n), l in zip(c2[1:], layers):
+                    _bias_grad_from_partials(cs2, i0, n, spec.cout, l.bias.grad, True)
+                c2 = cs2 = None
+        if _param_grads_pair(layers, spec, x, dy, group, colsum, [(ws[:per], splits), (ws[per:], splits)], colsum2=c2):
             return True
     # could not combine after all: the stashed batch on its own, then the ordinary path for this one
-    pp = conv_wgrad_pair_partial(spec, x2, dy2, g2)
-    if not (pp and _param_grads_pair(layers2, spec, x2, dy2, g2, None, pp, bias=False)):
-        for i, l in enumerate(layers2):
-            xs, dys = (x2[:g2], dy2[:g2]) if i == 0 else (x2[g2:], dy2[g2:])
-            conv_wgrad(spec, xs, dys, out=l.weight.grad, accumulate=True)
+    _stashed_alone(x2, dy2, g2, layers2, cs2)
     return False
+
+
+def _stashed_alone(x, dy, group, layers, cs):
+    """weight (and, if its column-sum partials `cs` are still pending, bias) gradients of a stashed batch by itself"""
+    spec = layers[0].spec
+    pp = conv_wgrad_pair_partial(spec, x, dy, group)
+    if pp and _param_grads_pair(layers, spec, x, dy, group, cs, pp, bias=cs is not None):
+        return
+    for i, l in enumerate(layers):
+        i0, n = (0, group) if i == 0 else (group, x.shape[0] - group)
+        conv_wgrad(spec, x[i0:i0 + n], dy[i0:i0 + n], out=l.weight.grad, accumulate=True, partial=pp[i] if pp else None)
+        if cs is not None:
+            _bias_grad_from_partials(cs, i0, n, spec.cout, l.bias.grad, True)
 
 
 class deferred_param_grads:
@@ -596,7 +607,7 @@ def _param_grads(layer, spec, x, dy, need_w, need_b, colsum=None, img0=0, partia
     return dW, db
 
 
-def _param_grads_pair(layers, spec, x, dy, group, colsum, pparts, bias=True):
+def _param_grads_pair(layers, spec, x, dy, group, colsum, pparts, bias=True, colsum2=None):
     """Both networks' dW (+ db) from a paired partial workspace in ONE reduce launch.  Only the training configuration
     (gradients accumulated in place into existing contiguous .grad buffers of both layers); returns False otherwise."""
     l1, l2 = layers
@@ -611,7 +622,16 @@ def _param_grads_pair(layers, spec, x, dy, group, colsum, pparts, bias=True):
     _, _, _, _, Np, _, _, Cq, _, D0, D1 = _wgrad_operands(spec, x, dy)
     rider = bias and colsum is not None and colsum[2] == dy.shape[3]
     lib = L.lib()
-    if rider:
+    if rider and colsum2 is not None:
+        # colsum2 = ((cpart, slabs per image, C), first image / images of network a, first image / images of network b) of the OTHER
+        # generator pass, whose weight-gradient partials are in the same workspace (_combined_wgrad)
+        cpart, spi, C = colsum
+        (cp2, spi2, _), (a0, an), (b0, bn) = colsum2
+        L.check(lib.uig_wgrad_reduce_pair2(_p(ws1), _p(l1.weight.grad), _p(l2.weight.grad), Np, Cq, k * k, splits, D0, D1, 1,
+                                           _p(cpart), _p(cpart[group * spi * C * 2:]), group * spi, (dy.shape[0] - group) * spi,
+                                           _p(cp2[a0 * spi2 * C * 2:]), _p(cp2[b0 * spi2 * C * 2:]), an * spi2, bn * spi2,
+                                           C, spec.cout, _p(l1.bias.grad), _p(l2.bias.grad), 1, _stream()), "uig_wgrad_reduce_pair2")
+    elif rider:
         cpart, spi, C = colsum
         ca, cb = cpart, cpart[group * spi * C * 2:]
         L.check(lib.uig_wgrad_reduce_pair(_p(ws1), _p(l1.weight.grad), _p(l2.weight.grad), Np, Cq, k * k, splits, D0, D1, 1, _p(ca), _p(cb),
@@ -689,6 +709,8 @@ def _conv_backward(ctx, dy, layers, group):
             grads, layers_left = [None] * (2 * npar), ()
             if par:      # a stashed batch is read by a later launch on the side stream
                 x.record_stream(side); dy.record_stream(side)
+                if colsum is not None:
+                    colsum[0].record_stream(side)
         else:
             pparts = conv_wgrad_pair_partial(spec, x, dy, group) if (npar == 2 and all(need_w) and PAIR_WGRAD) else None
         if combined:
