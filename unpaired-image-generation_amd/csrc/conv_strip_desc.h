@@ -68,9 +68,9 @@ __device__ __forceinline__ void strip_init_acc(f32x4_t (&acc)[NT][MT], const flo
 // residual adds, optional InstanceNorm partial statistics; full-row stores through this wave's 64x64 LDS scratch when its 64
 // channels are all stored, else direct 8/16-byte stores.  The bias is already in the accumulators (strip_init_acc).
 // The caller has made sure (barrier) that `scratch` is free.
-template <typename T, int MT, int NT, int WM, int WN, bool BORD = true>
+template <typename T, int MT, int NT, int WM, int WN, bool BORD = true, typename EHook = NoMidHook>
 __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], unsigned char* scratch, const StripDesc& d, T* __restrict__ y,
-                                               int img, int p0, int wm, int wn, int n_base, int lane) {
+                                               int img, int p0, int wm, int wn, int n_base, int lane, EHook ehook = EHook()) {
     const int HoWo = d.Ho * d.Wo;
     const int l16 = lane & 15, q = lane >> 4;
     const bool vec_ok = ((d.Nstore & 3) == 0) && ((d.ldc & 3) == 0);
@@ -83,7 +83,7 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
             so = d.in_partial + (((long)img * ((HoWo + 63) / 64) + pw / 64) * d.Nstore + nw0) * 2;
         auto rowp = [&](int r) -> T* { const int p = pw + r; return p < HoWo ? ybase + (long)p * d.ldc : nullptr; };
         if (d.border_add == nullptr && d.res_add == nullptr) {
-            store_tile_via_lds<T, MT, NT>(acc, scratch, lane, nullptr, d.act, d.slope, rowp, so, min(64, HoWo - pw));
+            store_tile_via_lds<T, MT, NT>(acc, scratch, lane, nullptr, d.act, d.slope, rowp, so, min(64, HoWo - pw), NoRowAdd(), ehook);   // ehook: diagnostic stamp
         } else {
             // reflection-pad dgrad: add the mirrored-border terms (phases T,B,L,R,TL,TR,BL,BR of the compact border buffer)
             constexpr int E = ElemTraits<T>::E;
@@ -140,6 +140,7 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
 #pragma unroll
                 for (int e = 0; e < E; ++e) { bmu[e] = 0.f; brs[e] = 0.f; bs1[e] = 0.f; bs2[e] = 0.f; }
                 auto mid = [&]() {                                     // the accumulators are dead here
+                    ehook();
                     if (!bst) return;
                     const float* sp = d.bst_stats + ((long)img * d.ldc + nw0 + c * E) * 2;
 #pragma unroll

@@ -31,9 +31,11 @@
 // - a ZERO-padded input gradient whose taps read a few "mirror pixels" (sums of two, at the four corners of four, pixels of dy)
 // in place of the pixel itself: output line 1 with dh = +1, line H-2 with dh = -1, column 1 with dw = +1, column W-2 with dw = -1.
 // The row table addresses pixels individually, so the mirror pixels are just extra strip slots behind the tile's NS pixels:
-//     NS + r, NS + 6 + r           column mirrors of strip line r: dy[r][2] + dy[r][0], dy[r][W-3] + dy[r][W-1]       (r < 6)
-//     NS + 12 + c  (c < 64)        line mirror (tile 0: dy[2][c] + dy[0][c]; last tile: dy[H-3][c] + dy[H-1][c])
-//     NS + 12 + 64, NS + 12 + 65   the line mirror's own column mirrors (four-pixel sums: the corner terms)
+//     NS + 8r + 2, NS + 8r + 5     column mirrors of strip line r: dy[r][2] + dy[r][0], dy[r][W-3] + dy[r][W-1]       (r < 6)
+//     NS + 48 + c  (c < 64)        line mirror (tile 0: dy[2][c] + dy[0][c]; last tile: dy[H-3][c] + dy[H-1][c])
+//     NS + 48 + 66, NS + 48 + 69   the line mirror's own column mirrors (four-pixel sums: the corner terms)
+// (a mirror pixel's slot has the low 3 bits of the pixel it stands in for - W is 64 - which is what the LDS bank group of a slot
+// depends on: the fragment reads keep the conflict-free pattern of 16 consecutive pixels)
 // summed in fp32 from the landed strip and rounded once to bf16, by all threads during the LAST tap-step of the previous chunk
 // (every strip piece of the chunk has landed and been published by then: pieces are issued in steps 0-6), visible to all after
 // the next step's barrier.  12 (+66) pixels x 8 chunks of work per K chunk against 36 x 512 MFMAs: nothing, and the 22-us
@@ -52,7 +54,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
     constexpr int ZW = CAP * 128 / SCRW;          // the wave whose scratch covers the region's zero row
     static_assert(CAP % 8 == 0 && PIECES <= NTAPS * NW, "one strip piece per wave per K-step");
     static_assert(!XPREF || (CAP * 128) % SCRW + 1024 <= SCRW, "zero row must lie inside one wave's scratch");
-    static_assert(!MIRROR || (sizeof(T) == 2 && SWZ == 1 && XPREF && 6 * 64 + 12 <= CAP && 5 * 64 + 12 + 66 <= CAP), "mirror pixels: bf16, 64-wide maps");
+    static_assert(!MIRROR || (sizeof(T) == 2 && SWZ == 1 && XPREF && 6 * 64 + 48 <= CAP && 5 * 64 + 48 + 72 <= CAP), "mirror pixels: bf16, 64-wide maps");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
 
@@ -166,7 +168,8 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] += g[e];
                 }
-                const int so = t.NS + px;
+                // slot: the low 3 bits of the pixel it stands in for (column 2 / W-3 of a line), so the fragment reads keep their bank pattern
+                const int so = t.NS + (px < 12 ? 8 * (px % 6) + (px >= 6 ? 5 : 2) : 48 + (px - 12 < 64 ? px - 12 : (px - 12 == 64 ? 66 : 69)));
                 *reinterpret_cast<u32x4_t*>(sb + so * 128 + (((k + (so & 6)) & 7) << 4)) = f32_to_chunk<T>(f);
             }
         }
@@ -207,27 +210,31 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
             const int dho = (pr * d.wo_magic) >> 20;                            // pr / Wo (exact: host-checked range)
             const int ho = ho0 + dho, wo = pr - dho * d.Wo;
             const bool pv = tl.p0 + wm * WM + b * 16 + l16 < HoWo;
-            int hrow[3], wcol[3];
+            // virtual strip index of tap (i, j)'s source pixel = hv[i] + wv[j]; out of range (zero padding) -> one of the eight zero
+            // slots CAP .. CAP+7, the one with the virtual index's low 3 bits: the slot's bank group is a function of (index & 7), so a
+            // fragment read keeps the conflict-free bank pattern of 16 consecutive pixels whether or not some of its lanes are padding
+            int hv[3], wv[3];
+            bool hok[3], wok[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int hi_ = ho + (d.tap[3 * i] & 255) - 128;
-                const bool ok = refl | ((unsigned)hi_ < (unsigned)d.H);
-                hrow[i] = ok ? ((refl ? reflect_idx(hi_, d.H) : hi_) - tl.lo) * d.W : -65536;
+                hok[i] = refl | ((unsigned)hi_ < (unsigned)d.H);
+                hv[i] = ((refl ? reflect_idx(hi_, d.H) : hi_) - tl.lo) * d.W;
                 const int wi_ = wo + ((d.tap[i] >> 8) & 255) - 128;
-                const bool okw = refl | ((unsigned)wi_ < (unsigned)d.W);
-                wcol[i] = okw ? (refl ? reflect_idx(wi_, d.W) : wi_) : -65536;
+                wok[i] = refl | ((unsigned)wi_ < (unsigned)d.W);
+                wv[i] = refl ? reflect_idx(wi_, d.W) : wi_;
             }
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) {
-                const int s0 = hrow[t / 3] + wcol[t % 3];
-                int s = (pv & (s0 >= 0)) ? s0 : CAP;
+                const int s0 = hv[t / 3] + wv[t % 3];
+                int s = (pv & hok[t / 3] & wok[t % 3]) ? s0 : CAP + (s0 & 7);
                 if constexpr (MIRROR) {                                         // taps that read a mirror pixel instead (kernel comment)
                     const int dh = (d.tap[3 * (t / 3)] & 255) - 128, dw = ((d.tap[t % 3] >> 8) & 255) - 128;
                     const bool ra = (ho == 1 && dh == 1) || (ho == d.H - 2 && dh == -1);
                     const bool cl = wo == 1 && dw == 1, cr = wo == d.W - 2 && dw == -1;
-                    if (s != CAP) {
-                        if (ra) s = tl.NS + 12 + (cl ? 64 : (cr ? 65 : wo + dw));
-                        else if (cl | cr) s = tl.NS + (cr ? 6 : 0) + (ho + dh - tl.lo);
+                    if (s < CAP) {
+                        if (ra) s = tl.NS + 48 + (cl ? 66 : (cr ? 69 : wo + dw));
+                        else if (cl | cr) s = tl.NS + 8 * (ho + dh - tl.lo) + (cr ? 5 : 2);
                     }
                 }
                 rt[t][b] = (unsigned short)(s * 128 + ((SWZ ? ((q + (s & 6)) & 7) : (q ^ ((s >> 1) & 7))) << 4));
@@ -241,7 +248,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
         const Tile nxt = get_tile(r + 1);
         if (cur.ti != rt_ti) { build_rt(cur); rt_ti = cur.ti; }
         if constexpr (MIRROR) {
-            if (r == 0) {                                       // the block's first chunk: nothing ran in front of it to hide this behind
+            if (r == 0 && !(d.mirror & 4)) {                                       // the block's first chunk: nothing ran in front of it to hide this behind
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 mirror_fix(0, cur);
@@ -328,7 +335,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                 if constexpr (MIRROR) {
                     // last step of the chunk: the next chunk's strip (issued in steps 0-6) is complete and published; its mirror
                     // pixels are published by the next step's barrier
-                    if (last_t && s_on) mirror_fix(pc ^ 1, last_cc ? nxt : cur);
+                    if (last_t && s_on && !(d.mirror & 2)) mirror_fix(pc ^ 1, last_cc ? nxt : cur);
                 }
             }
         }
@@ -344,6 +351,10 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
         // spilled to scratch, reloaded one `s_waitcnt vmcnt(0)` at a time behind the epilogue's own global stores).
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
+        if constexpr (STAMP) {                                  // + after the barrier / after the tile's LDS writes
+            stamp();
+            strip_epilogue<T, MT, NT, WM, WN, !MIRROR>(acc, scratch, d, y, cur.img, cur.p0, wm, wn, cur.n_base, lane_e, stamp);
+        } else
         strip_epilogue<T, MT, NT, WM, WN, !MIRROR>(acc, scratch, d, y, cur.img, cur.p0, wm, wn, cur.n_base, lane_e);
         stamp();                                               // 3 / 6: epilogue issued
         if (!nxt.valid) break;
@@ -413,7 +424,8 @@ int uig_launch_strip_pk(const void* x, const void* wp, const float* bias, void* 
     const int tpi = (d.Ho * d.Wo + 255) / 256;
     const int ntiles = d.B * tpi * (d.Nrows / 128);
     if (dtype == UIG_BF16) {
-        if (d.mirror) return launch_pk<bf16_t, 448, 0, 1, true, false, true>(x, wp, bias, y, d, ntiles, s);
+        if (d.mirror) return d.dbg != nullptr ? launch_pk<bf16_t, 448, 0, 1, true, true, true>(x, wp, bias, y, d, ntiles, s)
+                                              : launch_pk<bf16_t, 448, 0, 1, true, false, true>(x, wp, bias, y, d, ntiles, s);
         if (d.dbg != nullptr) return launch_pk<bf16_t, 448, 0, 1, true, true>(x, wp, bias, y, d, ntiles, s);
         switch (g_pk_dm) {      // tuning variants (A/B in one process: scripts/bench_strip_pk.py)
             case 2: return launch_pk<bf16_t, 448, 0, 0, true>(x, wp, bias, y, d, ntiles, s);      // XOR swizzle (for the bank-conflict counters)

@@ -98,26 +98,35 @@ __device__ __forceinline__ void store_tile_via_lds(const f32x4_t (&acc)[NT][MT],
     constexpr int ROWB = 64 * (int)sizeof(T);          // 128 (bf16) / 256 (f32) bytes per pixel row
     constexpr int NCH = ROWB / 16;                     // 16-byte chunks per row
     const int l16 = lane & 15, q = lane >> 4;
+    // The activation is a launch constant: ONE branch around the whole conversion loop, not a switch per element.  With the switch
+    // inside, each of the 64 elements carried an inlined tanhf body to jump over: ~20k instructions of epilogue whose fetch (not
+    // its arithmetic) cost 7.5k cycles per tile in the persistent strip kernel (s_memtime stamps).
+    auto to_lds = [&](auto actf) {
 #pragma unroll
-    for (int b = 0; b < MT; ++b) {
-        const int m = b * 16 + l16;
+        for (int b = 0; b < MT; ++b) {
+            const int m = b * 16 + l16;
 #pragma unroll
-        for (int a = 0; a < NT; ++a) {
-            float v[4];
+            for (int a = 0; a < NT; ++a) {
+                float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[a][b][e] + (bias4 ? bias4[a * 4 + e] : 0.f), act, slope);
-            if constexpr (sizeof(T) == 4) {
-                const int chunk = (4 * a + q) ^ (m & (NCH - 1));
-                *reinterpret_cast<f32x4_t*>(scratch + m * ROWB + chunk * 16) = f32x4_t{v[0], v[1], v[2], v[3]};
-            } else {
-                const int chunk = (2 * a + (q >> 1)) ^ (m & (NCH - 1));
-                u32x2_t pk;
-                pk[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                pk[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-                *reinterpret_cast<u32x2_t*>(scratch + m * ROWB + chunk * 16 + (q & 1) * 8) = pk;
+                for (int e = 0; e < 4; ++e) v[e] = actf(acc[a][b][e] + (bias4 ? bias4[a * 4 + e] : 0.f));
+                if constexpr (sizeof(T) == 4) {
+                    const int chunk = (4 * a + q) ^ (m & (NCH - 1));
+                    *reinterpret_cast<f32x4_t*>(scratch + m * ROWB + chunk * 16) = f32x4_t{v[0], v[1], v[2], v[3]};
+                } else {
+                    const int chunk = (2 * a + (q >> 1)) ^ (m & (NCH - 1));
+                    u32x2_t pk;
+                    pk[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                    pk[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                    *reinterpret_cast<u32x2_t*>(scratch + m * ROWB + chunk * 16 + (q & 1) * 8) = pk;
+                }
             }
         }
-    }
+    };
+    if (act == UIG_ACT_NONE) to_lds([](float v) { return v; });
+    else if (act == UIG_ACT_RELU) to_lds([](float v) { return v > 0.f ? v : 0.f; });
+    else if (act == UIG_ACT_LRELU) to_lds([slope](float v) { return v > 0.f ? v : v * slope; });
+    else to_lds([](float v) { return tanhf(v); });
     // The tile is written as 8-byte / f32x4 vectors and read back as u32x4: different vector types, which type-based alias
     // analysis may treat as non-aliasing (seen in conv_cin8.hip: reads scheduled above the writes).  Compiler barrier.
     asm volatile("" ::: "memory");
