@@ -122,12 +122,11 @@ int uig_conv_strip_applicable(int B, int H, int W, int Cin, int Nrows, int Ho, i
  * pixels": sums of two - at the corners four - pixels of dy placed behind the tile's LDS strip and addressed by the taps that
  * would have read a mirrored line or column; bf16, 64-pixel-wide maps of >= 8 lines, C % 64 == 0, Nrows == ldc, Nrows % 128 == 0):
  * dx (B, H, W, ldc) = zero-padded transposed conv of dy (B, H, W, C) + mirrored terms [+ res_add of dx's shape].  No border
- * buffer, no border GEMM in front.  uig_reflect3x3_dgrad_mirror_applicable: 1 where it applies, else use the two launches above.
- * bst_* as uig_conv_gather_bst (all NULL / 0: none; needs res_add). */
+ * buffer, no border GEMM in front.  uig_reflect3x3_dgrad_mirror_applicable: 1 where it applies, else use the two launches above
+ * (which also carry the optional fused norm-backward statistics of uig_conv_gather_bst; this launch does not). */
 int uig_reflect3x3_dgrad_mirror_applicable(int B, int H, int W, int C, int Nrows, int ldc, int dtype);
 int uig_reflect3x3_dgrad_mirror(const void* dy, const void* wp, const void* wp2, int group_images, const void* res_add, void* dx,
-                                int B, int H, int W, int C, int Nrows, int ldc, int dtype,
-                                const void* bst_x, const float* bst_stats, int bst_act, float bst_slope, float* bst_partial, void* stream);
+                                int B, int H, int W, int C, int Nrows, int ldc, int dtype, void* stream);
 
 /* ---- MX block-scaled fp8 path (BASELINE.json configs[4]): the 3x3 stride-1 pad-1 convolutions (forward: gather_mode direct,
  * zero or reflection padding; input gradient: gather_mode transposed, zero padding + border_add) on

@@ -65,7 +65,7 @@ for pm in ("reflect", "zero"):
         dxz = torch.empty(B, 64, 64, 256, device=dev, dtype=dt)
         def mk(dy=dy, ls=ls, dxz=dxz):
             u.lib.check(lib.uig_reflect3x3_dgrad_mirror(dy.data_ptr(), ls[0].wp_dgrad.data_ptr(), ls[1].wp_dgrad.data_ptr(), g, None, dxz.data_ptr(),
-                                                        B, 64, 64, 256, 256, 256, u.lib.BF16, None, None, 0, 0.0, None, torch.cuda.current_stream().cuda_stream), "mirror")
+                                                        B, 64, 64, 256, 256, 256, u.lib.BF16, torch.cuda.current_stream().cuda_stream), "mirror")
         cases["zero-layer operands, mirror kernel"] = make_graph(mk)
         lib.uig_debug_set_mirror(7)
         cases["zero-layer operands, mirror kernel no fix"] = make_graph(mk)

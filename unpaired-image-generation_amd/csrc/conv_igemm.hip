@@ -571,16 +571,12 @@ extern "C" int uig_conv_gather_bst(const void* x, const void* wp, const float* b
 // Input gradient of a reflection-padded (pad 1) 3x3 stride-1 convolution in ONE launch: dx (B, H, W, ldc) = the zero-padded
 // transposed convolution of dy (B, H, W, C) with the mirrored-border terms folded inside the persistent strip kernel (mirror pixels,
 // conv_strip_pk.hip) [+ res_add, a tensor of dx's shape: the ResBlock skip gradient].  wp / wp2 + group_images as uig_conv_gather_pair
-// (the packed TRANSPOSED-gather operands).  Only where uig_reflect3x3_dgrad_mirror_applicable says 1.  bst_*: optional, as
-// uig_conv_gather_bst (all null / 0 = none).
+// (the packed TRANSPOSED-gather operands).  Only where uig_reflect3x3_dgrad_mirror_applicable says 1.
 extern "C" int uig_reflect3x3_dgrad_mirror(const void* dy, const void* wp, const void* wp2, int group_images, const void* res_add, void* dx,
-                                           int B, int H, int W, int C, int Nrows, int ldc, int dtype,
-                                           const void* bst_x, const float* bst_stats, int bst_act, float bst_slope, float* bst_partial, void* stream) {
+                                           int B, int H, int W, int C, int Nrows, int ldc, int dtype, void* stream) {
     UIG_CHECK_ARG(dy && wp && dx, "uig_reflect3x3_dgrad_mirror: null pointer");
-    UIG_CHECK_ARG((bst_x != nullptr) == (bst_stats != nullptr) && (bst_x != nullptr) == (bst_partial != nullptr), "uig_reflect3x3_dgrad_mirror: bst_x, bst_stats and bst_partial go together");
-    const UigBst b{bst_x, bst_stats, bst_partial, bst_act, bst_slope};
     return conv_gather_impl(dy, wp, nullptr, wp2, nullptr, wp2 ? group_images : 0, nullptr, nullptr, res_add, dx, B, H, W, C, Nrows, 3, 3, 1, 1, UIG_PAD_ZERO,
-                            UIG_GATHER_TRANSPOSED, H, W, ldc, ldc, UIG_ACT_NONE, 0.f, dtype, stream, bst_x ? &b : nullptr, 1);
+                            UIG_GATHER_TRANSPOSED, H, W, ldc, ldc, UIG_ACT_NONE, 0.f, dtype, stream, nullptr, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

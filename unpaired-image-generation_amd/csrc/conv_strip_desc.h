@@ -102,17 +102,21 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
                 const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<void*>(hasr ? d.res_add : d.border_add), 0, hasr ? (unsigned)((long)d.B * HoWo * d.ldc * (int)sizeof(T)) : 0u, 0x00020000);
                 constexpr int NI = 8;                                  // 64 rows / 8 rows per store instruction
-                constexpr int ND = 2;                                  // rows in flight: a ring of ND prefetch slots, refilled as rows are stored (2 and 4 measure the same; 4 spills with the statistics path)
+                // rows in flight: a ring of ND prefetch slots, refilled as rows are stored.  With border terms 2 and 4 measure the same
+                // and 4 spills with the statistics path; without them (mirror-pixel kernel: one chunk per row) all 8 rows are fetched up
+                // front - the ring of 2 left ~4 exposed round trips: 6.7k cycles per tile by the stamps
+                constexpr int ND = BORD ? 2 : 8;
                 const int c = lane % 8, r0 = lane / 8;
                 auto boff = [&](int phase, int pos) -> int {
                     return (int)(((((long)img * 8 + phase) * S + pos) * d.ldc + nw0 + c * E) * (long)sizeof(T));
                 };
                 // statistics of the InstanceNorm backward that takes this output as its dy (bst_*): the norm's saved input is
                 // prefetched like the residual; (sum g, sum g * xhat) of the lane's 8 channels over its 8 rows, combined below
-                const bool bst = d.bst_partial != nullptr && pw < HoWo;                 // wave-uniform
+                const bool bst = BORD && d.bst_partial != nullptr && pw < HoWo;         // wave-uniform; not in the mirror-pixel kernel (refused on the host)
                 const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<void*>(bst ? d.bst_x : (hasr ? d.res_add : d.border_add)), 0, bst ? (unsigned)((long)d.B * HoWo * d.ldc * (int)sizeof(T)) : 0u, 0x00020000);
-                u32x4_t pre[ND][BORD ? 2 : 1], prex[ND];               // [border term (line or column),] residual tensor; the norm's input
+                constexpr int NDX = 2;                                 // ring of the norm's-input chunks (bst_* statistics)
+                u32x4_t pre[ND][BORD ? 2 : 1], prex[NDX];              // [border term (line or column),] residual tensor; the norm's input
                 constexpr int PR = BORD ? 1 : 0;                       // slot of the residual chunk
                 unsigned both = 0;                                     // bit i: row i is one of the image's four double-border pixels
                 auto fetch = [&](int i) {                              // row i -> slot i % ND (static after unrolling)
@@ -131,16 +135,19 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
                 };
                 auto fetch_x = [&](int i) {
                     const int p = pw + r0 + 8 * i;
-                    prex[i % ND] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                    prex[i % NDX] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
                         rsn, (bst & (p < HoWo)) ? (int)((((long)img * HoWo + p) * d.ldc + nw0 + c * E) * (long)sizeof(T)) : -1, 0, 0));
                 };
+                constexpr int ND0 = 2;                                 // fetched NOW, behind the LDS transposition (accumulators still live); the rest in mid()
 #pragma unroll
-                for (int i = 0; i < ND; ++i) fetch(i);                 // behind the LDS transposition
+                for (int i = 0; i < ND0; ++i) fetch(i);
                 float bmu[E], brs[E], bs1[E], bs2[E];
 #pragma unroll
                 for (int e = 0; e < E; ++e) { bmu[e] = 0.f; brs[e] = 0.f; bs1[e] = 0.f; bs2[e] = 0.f; }
                 auto mid = [&]() {                                     // the accumulators are dead here
                     ehook();
+#pragma unroll
+                    for (int i = ND0; i < ND; ++i) fetch(i);
                     if (!bst) return;
                     const float* sp = d.bst_stats + ((long)img * d.ldc + nw0 + c * E) * 2;
 #pragma unroll
@@ -149,7 +156,7 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
                         bmu[e] = t4[0]; brs[e] = t4[1]; bmu[e + 1] = t4[2]; brs[e + 1] = t4[3];
                     }
 #pragma unroll
-                    for (int i = 0; i < ND; ++i) fetch_x(i);
+                    for (int i = 0; i < NDX; ++i) fetch_x(i);
                 };
                 auto add = [&](int r, int, const u32x4_t& v, int i) -> u32x4_t {
                     float f[E], g[E];
@@ -177,7 +184,7 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
                     if (bst) {                                         // on the values AS STORED (what the norm's own pass would read back)
                         float gv[E], xv[E];
                         chunk_to_f32<T>(outc, gv);
-                        chunk_to_f32<T>(prex[i % ND], xv);
+                        chunk_to_f32<T>(prex[i % NDX], xv);
                         const bool in = pw + r < HoWo;
 #pragma unroll
                         for (int e = 0; e < E; ++e) {
@@ -189,7 +196,8 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
                             bs1[e] += gg; bs2[e] += gg * xh;
                         }
                     }
-                    if (i + ND < NI) { fetch(i + ND); if (bst) fetch_x(i + ND); }      // refill the slot just consumed
+                    if (i + ND < NI) fetch(i + ND);                    // refill the slot just consumed
+                    if (bst && i + NDX < NI) fetch_x(i + NDX);
                     return outc;
                 };
                 store_tile_via_lds<T, MT, NT>(acc, scratch, lane, nullptr, d.act, d.slope, rowp, so, min(64, HoWo - pw), add, mid);

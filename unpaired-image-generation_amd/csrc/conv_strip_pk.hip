@@ -201,43 +201,59 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
     //      Taps form a 3x3 grid: dh depends on t / 3 only, dw on t % 3 only (checked on the host).
     unsigned short rt[NTAPS][MT];
     int rt_ti = -1;
+    // Every lane builds its own table (8 waves x 2 per SIMD on the VALU: ~8 cycles per instruction at the head of the launch), so
+    // the address is kept SEPARABLE: W is a multiple of 16 (host-checked), hence the swizzle term of slot hv + wv depends on wv
+    // only and address(i, j) = A_i + B_j: 3 + 3 values per pixel group, one add and one select per table entry (the first form
+    // swizzled each of the 36 entries: ~1000 VALU instructions, 10k cycles of prologue by the stamps; 23k with the mirror cases).
     auto build_rt = [&](const Tile& tl) {
         const bool refl = d.pad_mode == UIG_PAD_REFLECT;
         const int ho0 = tl.p0 / d.Wo, rem0 = tl.p0 - ho0 * d.Wo;              // scalar
+        auto swz = [&](int x) -> int { return (SWZ ? ((q + (x & 6)) & 7) : (q ^ ((x >> 1) & 7))) << 4; };   // x: slot index mod 16
+        int dhs[3], dws[3];                                                    // scalar
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { dhs[i] = (d.tap[3 * i] & 255) - 128; dws[i] = ((d.tap[i] >> 8) & 255) - 128; }
 #pragma unroll
         for (int b = 0; b < MT; ++b) {
             const int pr = rem0 + wm * WM + b * 16 + l16;                       // < Wo + 256
             const int dho = (pr * d.wo_magic) >> 20;                            // pr / Wo (exact: host-checked range)
             const int ho = ho0 + dho, wo = pr - dho * d.Wo;
             const bool pv = tl.p0 + wm * WM + b * 16 + l16 < HoWo;
-            // virtual strip index of tap (i, j)'s source pixel = hv[i] + wv[j]; out of range (zero padding) -> one of the eight zero
-            // slots CAP .. CAP+7, the one with the virtual index's low 3 bits: the slot's bank group is a function of (index & 7), so a
-            // fragment read keeps the conflict-free bank pattern of 16 consecutive pixels whether or not some of its lanes are padding
-            int hv[3], wv[3];
+            // source pixel of tap (i, j) = strip slot hv_i + wv_j; out of range (zero padding) -> one of the eight zero slots
+            // CAP .. CAP+7, the one with the column's low 3 bits: a slot's bank group is a function of (slot & 7), so a fragment read
+            // keeps the conflict-free bank pattern of 16 consecutive pixels whether or not some of its lanes are padding
+            int A[3], Bj[3], Z[3];
             bool hok[3], wok[3];
+            [[maybe_unused]] int CA[3], TA[3];
+            [[maybe_unused]] bool ra[3], ca[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int hi_ = ho + (d.tap[3 * i] & 255) - 128;
-                hok[i] = refl | ((unsigned)hi_ < (unsigned)d.H);
-                hv[i] = ((refl ? reflect_idx(hi_, d.H) : hi_) - tl.lo) * d.W;
-                const int wi_ = wo + ((d.tap[i] >> 8) & 255) - 128;
+                const int hi_ = ho + dhs[i];
+                hok[i] = pv & (refl | ((unsigned)hi_ < (unsigned)d.H));
+                A[i] = ((refl ? reflect_idx(hi_, d.H) : hi_) - tl.lo) * d.W * 128;
+                const int wi_ = wo + dws[i];
                 wok[i] = refl | ((unsigned)wi_ < (unsigned)d.W);
-                wv[i] = refl ? reflect_idx(wi_, d.W) : wi_;
+                const int wvi = refl ? reflect_idx(wi_, d.W) : wi_;
+                const int sw = swz(wvi);
+                Bj[i] = wvi * 128 + sw;
+                Z[i] = (CAP + (wvi & 7)) * 128 + sw;
+                if constexpr (MIRROR) {                                         // taps that read a mirror pixel instead (kernel comment)
+                    ra[i] = (ho == 1 && dhs[i] == 1) || (ho == d.H - 2 && dhs[i] == -1);
+                    CA[i] = (tl.NS + 8 * (hi_ - tl.lo)) * 128;                  // column mirrors of the tap's source line
+                    const bool cl = wo == 1 && dws[i] == 1, cr = wo == d.W - 2 && dws[i] == -1;
+                    ca[i] = cl | cr;
+                    const int c = cr ? 5 : 2;
+                    if (ca[i]) Bj[i] = c * 128 + swz(c);                        // behind CA_i instead of A_i
+                    const int x = cl ? 66 : (cr ? 69 : wvi);
+                    TA[i] = (tl.NS + 48 + x) * 128 + swz(x);                    // line mirror (and its own column mirrors)
+                }
             }
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) {
-                const int s0 = hv[t / 3] + wv[t % 3];
-                int s = (pv & hok[t / 3] & wok[t % 3]) ? s0 : CAP + (s0 & 7);
-                if constexpr (MIRROR) {                                         // taps that read a mirror pixel instead (kernel comment)
-                    const int dh = (d.tap[3 * (t / 3)] & 255) - 128, dw = ((d.tap[t % 3] >> 8) & 255) - 128;
-                    const bool ra = (ho == 1 && dh == 1) || (ho == d.H - 2 && dh == -1);
-                    const bool cl = wo == 1 && dw == 1, cr = wo == d.W - 2 && dw == -1;
-                    if (s < CAP) {
-                        if (ra) s = tl.NS + 48 + (cl ? 66 : (cr ? 69 : wo + dw));
-                        else if (cl | cr) s = tl.NS + 8 * (ho + dh - tl.lo) + (cr ? 5 : 2);
-                    }
-                }
-                rt[t][b] = (unsigned short)(s * 128 + ((SWZ ? ((q + (s & 6)) & 7) : (q ^ ((s >> 1) & 7))) << 4));
+                const int i = t / 3, j = t % 3;
+                int a;
+                if constexpr (MIRROR) a = ra[i] ? TA[j] : (ca[j] ? CA[i] : A[i]) + Bj[j];
+                else a = A[i] + Bj[j];
+                rt[t][b] = (unsigned short)((hok[i] & wok[j]) ? a : Z[j]);
             }
         }
     };
@@ -288,6 +304,13 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                     else if (p_on) issue_strip_piece(slot, s_base, s_NS, pc ^ 1);
                 };
                 if constexpr (DM == 0 || DM == 4) { dma(0); dma(1); dma(2); }
+                if constexpr (MIRROR) {
+                    // last step of the chunk: the next chunk's strip (issued in steps 0-6) is complete and published by this step's
+                    // barrier; its mirror pixels are written HERE, at the top of the step, while the matrix pipe still works off the
+                    // previous step's MFMAs (at the end of the step the round trip through the LDS sat exposed in front of the next
+                    // barrier: +2.5k cycles per tile by the stamps), and are published by the next step's barrier
+                    if (last_t && s_on && !(d.mirror & 2)) mirror_fix(pc ^ 1, last_cc ? nxt : cur);
+                }
                 const unsigned char* sw = smem + (pc ^ (t & 1)) * REG + SBUF + (wn * WN + l16) * 128;
                 if constexpr (DM == 3) {                        // all 16 fragment reads of the step first, then the DMAs, then 32 MFMAs
                     u32x4_t xf[2][MT], wf[2][NT];
@@ -331,11 +354,6 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                     }
                     if constexpr (DM == 4) __builtin_amdgcn_s_setprio(0);
                 }
-                }
-                if constexpr (MIRROR) {
-                    // last step of the chunk: the next chunk's strip (issued in steps 0-6) is complete and published; its mirror
-                    // pixels are published by the next step's barrier
-                    if (last_t && s_on && !(d.mirror & 2)) mirror_fix(pc ^ 1, last_cc ? nxt : cur);
                 }
             }
         }
@@ -413,7 +431,7 @@ static int launch_pk(const void* x, const void* wp, const float* bias, void* y, 
 // 1 if the persistent kernel can take this 256x128-tile launch (d filled by uig_try_conv_strip): taps must form a 3x3 grid
 // (dh a function of t / 3, dw of t % 3) and the in-tile division by Wo must be exact in 20-bit fixed point.
 bool uig_strip_pk_ok(const StripDesc& d, int need256) {
-    if (need256 > 448 || d.Wo > 512) return false;
+    if (need256 > 448 || d.Wo > 512 || d.W % 16 != 0) return false;      // W % 16: the row table's separable swizzle (build_rt)
     for (int t = 0; t < 9; ++t)
         if ((d.tap[t] & 255) != (d.tap[3 * (t / 3)] & 255) || ((d.tap[t] >> 8) & 255) != ((d.tap[t % 3] >> 8) & 255)) return false;
     return true;

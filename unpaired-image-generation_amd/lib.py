@@ -38,7 +38,7 @@ SIGNATURES = {
     "uig_conv_gather_bst": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp] + [_i] * 15 + [_i, _f, _i] + [_vp, _vp, _i, _f, _vp] + [_vp]),
     "uig_reflect3x3_dgrad_border": (_i, [_vp, _vp, _vp, _i, _vp] + [_i] * 7 + [_vp]),
     "uig_reflect3x3_dgrad_mirror_applicable": (_i, [_i] * 7),
-    "uig_reflect3x3_dgrad_mirror": (_i, [_vp, _vp, _vp, _i, _vp, _vp] + [_i] * 7 + [_vp, _vp, _i, _f, _vp, _vp]),
+    "uig_reflect3x3_dgrad_mirror": (_i, [_vp, _vp, _vp, _i, _vp, _vp] + [_i] * 7 + [_vp]),
     "uig_conv_strip_applicable": (_i, [_i] * 10),
     "uig_conv_strip_tile": (_i, [_i] * 10),
     "uig_conv3x3_mx_fp8_applicable": (_i, [_i] * 5),

@@ -437,7 +437,7 @@ def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, 
     # pad-1 reflection 3x3 on 64-wide bf16 maps (the ResBlock convs at 256x256): the persistent strip kernel folds the mirrored
     # terms itself (mirror pixels, uig_reflect3x3_dgrad_mirror) - one launch, square map or not
     mirror = (spec.kind == "conv" and spec.reflect and spec.k == 3 and spec.pad == 1 and spec.stride == 1 and REFLECT_DGRAD_DIRECT
-              and mx is None and spec.cin_p == spec.cin
+              and mx is None and spec.cin_p == spec.cin and not (bst is not None and FUSE_BWD_STATS)
               and L.lib().uig_reflect3x3_dgrad_mirror_applicable(B, Ho, Wo, Cd, spec.cin, spec.cin_p, _dt(dy)) == 1)
     if res_add is not None:
         fusable = (spec.kind == "conv" and spec.reflect and spec.k == 3 and spec.pad == 1 and spec.stride == 1 and ((H == W and 4 <= H <= 128) or mirror)
@@ -477,11 +477,8 @@ def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, 
             _conv3x3_mx(dq, ds, mx, None, None, pair[2] if pair is not None else 0, dx, spec.cin, L.PAD_ZERO, L.GATHER_TRANSPOSED,
                         L.ACT_NONE, 0.0, None, bord, res_add, bst)
         elif mirror:
-            if bst is not None and res_add is None:
-                bst, bpart = None, None
-            b5 = (_p(bst[0]), _p(bst[1]), bst[2], bst[3], _p(bst[4])) if bst is not None else (None, None, 0, 0.0, None)
             L.check(lib.uig_reflect3x3_dgrad_mirror(_p(dy), _p(wp_dgrad), _p(wp2), g, _p(res_add), _p(dx), B, Ho, Wo, Cd, spec.cin, spec.cin_p,
-                                                    _dt(dy), *b5, s), "uig_reflect3x3_dgrad_mirror")
+                                                    _dt(dy), s), "uig_reflect3x3_dgrad_mirror")
         else:
             _gather(dy, wp_dgrad, None, dx, B, Ho, Wo, Cd, spec.cin, spec, 1, 1, L.PAD_ZERO, L.GATHER_TRANSPOSED, H, W, spec.cin_p,
                     L.ACT_NONE, 0.0, "uig_conv_gather(dgrad+border)", pair, None, bord, res_add, bst)
