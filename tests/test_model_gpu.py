@@ -456,6 +456,33 @@ def test_combined_pass_weight_gradient_equals_separate(graph, monkeypatch):
     m0.close(); m1.close()
 
 
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
+def test_side_streams_equal_single_stream(graph, monkeypatch):
+    """The stream-parallel form of the step (parameter-gradient kernels on a side stream joined once per phase, generator update
+    on its own stream under the discriminator phase - the defaults of round 1, now opt-in / data-parallel only because they
+    measure slower on one GPU) against the single-stream default: the same kernels on the same data in another interleaving,
+    so losses and parameters must agree bitwise over 3 steps."""
+    import unpaired_image_generation_amd as u
+    ops = u.ops
+    torch.manual_seed(23)
+    rA, rB = (torch.rand(2, 3, 64, 64, device="cuda") * 2 - 1 for _ in range(2))
+    torch.manual_seed(7)
+    monkeypatch.setattr(ops, "PARALLEL_BACKWARD", False)
+    monkeypatch.setenv("UIG_OVERLAP_UPDATE", "0")
+    m0 = u.CycleGAN(n_blocks=3, dtype=torch.bfloat16, use_graph=graph)
+    assert not m0.overlap_update
+    l0 = [m0.train_step(rA, rB) for _ in range(3)]
+    monkeypatch.setattr(ops, "PARALLEL_BACKWARD", True)
+    monkeypatch.setenv("UIG_OVERLAP_UPDATE", "1")
+    torch.manual_seed(7)
+    m2 = u.CycleGAN(n_blocks=3, dtype=torch.bfloat16, use_graph=graph)      # same seed as m0: same initial weights
+    assert m2.overlap_update
+    l2 = [m2.train_step(rA, rB) for _ in range(3)]
+    assert l0 == l2, (l0, l2)
+    assert torch.equal(m0.grp_G.flat, m2.grp_G.flat) and torch.equal(m0.grp_D.flat, m2.grp_D.flat)
+    m0.close(); m2.close()
+
+
 def test_graph_step_with_rccl_exchange_world1_and_close():
     """Guards two aborts seen in round 1 (graph capture with a live process group; process exit with graphs + RCCL alive).
     One worker process = one rank, as in production (the process group lives as long as the process):

@@ -52,8 +52,10 @@ class CycleGAN:
         self.use_graph, self.batch_fused, self.paired = use_graph, batch_fused, paired
         # parameter-gradient kernels stay on the side stream across layers and are joined once per phase (see ops.deferred_param_grads)
         self.defer_join = os.environ.get("UIG_DEFER_JOIN", "1") != "0"
-        # generator update (exchange wait, Adam, repack) on its own stream under the discriminator phase (0: after it, on the main stream)
-        self.overlap_update = os.environ.get("UIG_OVERLAP_UPDATE", "1") != "0"
+        # generator update (exchange wait, Adam, repack) on its own stream under the discriminator phase (0: after it, on the main
+        # stream).  Default: only when gradients are exchanged (the wait for the all-reduce is what it hides); on one GPU the
+        # second stream measured slower (see ops.PARALLEL_BACKWARD)
+        self.overlap_update = os.environ.get("UIG_OVERLAP_UPDATE", "1" if self.xchg.active else "0") != "0"
         # data-parallel gradient buckets: the backward pass of each phase is cut into stages and each stage's slice of the flat
         # gradient buffer is all-reduced under the next stage (dp.staged_backward / run_exchange_phase).  One stage (= the
         # single-GPU step, bit for bit) when no collective is issued.

@@ -19,7 +19,11 @@ from . import lib as L
 REFLECT_DGRAD_DIRECT = os.environ.get("UIG_REFLECT_DGRAD_DIRECT", "1") != "0"   # 3x3 reflect-pad convs: input gradient on the exact grid + border GEMM (no padded gradient, no fold)
 PAIR_WGRAD = os.environ.get("UIG_PAIR_WGRAD", "1") != "0"                   # paired layers: both networks' weight-gradient partials in one launch where the library supports it
 FUSE_SKIP_GRAD = os.environ.get("UIG_FUSE_SKIP_GRAD", "1") != "0"           # ResBlock: the skip path's gradient is added in conv1's input-gradient epilogue instead of by a separate add kernel
-PARALLEL_BACKWARD = os.environ.get("UIG_PARALLEL_BACKWARD", "1") != "0"      # run a conv's parameter-gradient kernels concurrently with its input-gradient kernel
+# Run a conv's parameter-gradient kernels on a side stream beside its input-gradient kernel.  OFF by default since round 2: the
+# MFMA kernels of the backward pass (strip dgrad: 149.5 KB LDS, 246 VGPRs x 2 waves per SIMD; image-row wgrad: 132 KB, same
+# registers) each fill a CU on their own, so two of them never share one and the HBM-bound InstanceNorm kernels find no free
+# register file beside them either - the second stream only adds contention: 14.01 vs 14.25 ms per step (two boxes, A/B in one call).
+PARALLEL_BACKWARD = os.environ.get("UIG_PARALLEL_BACKWARD", "0") != "0"
 # InstanceNorm backward statistics (sum g, sum g*xhat) from the epilogue of the input-gradient launch that writes the norm's dy,
 # instead of the norm's own pass over dy and x.  OFF by default: measured on MI355X (scripts/bench_dgrad_nd.py, paired 16-image
 # launch) the epilogue work costs +13.7 us against the 17 us statistics kernel it removes (+9.2 vs 9 us at 8 images); whole step
