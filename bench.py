@@ -42,7 +42,7 @@ def main():
                     help="fp8: BASELINE configs[4] (use --batch 8): ResBlock convs fwd + dgrad on MX block-scaled fp8 MFMA, bf16 elsewhere")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kernel-iters", type=int, default=100)
+    ap.add_argument("--kernel-iters", type=int, default=300, help="timed launches / 2 of the dominant kernel (3x this many back-to-back, the first third is warm-up)")
     ap.add_argument("--force-comm", action="store_true", help="run the RCCL exchange even at world size 1 (plumbing test)")
     args = ap.parse_args()
 
