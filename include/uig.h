@@ -196,8 +196,8 @@ int uig_wgrad_partial_pair(const void* P, const void* Q, float* workspace, int B
 /* The same over TWO batches in one launch: the step's two generator passes use the same two weight sets - pass 1 on (P, Q) =
  * B1 images of which the first g1 are network 0's, pass 2 on (P2, Q2) = B2 images of which the first g2 are network
  * (swap2 ? 1 : 0)'s.  The fixed cost of a split-K launch (fill / drain, partial slabs, reduce) is paid once.
- * uig_wgrad_pair2_splits: split count to use, 0 = the image-row kernel does not take this shape (run the two launches).
- * Workspace and reduce as for uig_wgrad_partial_pair. */
+ * uig_wgrad_pair2_splits: the split count to use (the generic kernel accepts exactly this value), 0 = run the two launches
+ * (bad grouping, or the 7x7 head kernel's shape).  Workspace and reduce as for uig_wgrad_partial_pair. */
 int uig_wgrad_pair2_splits(int B1, int g1, int B2, int g2, int swap2, int Mh, int Mw, int Np, int Hq, int Wq, int Cq,
                            int kH, int kW, int stride, int pad, int dtype);
 int uig_wgrad_partial_pair2(const void* P, const void* Q, const void* P2, const void* Q2, float* workspace,

@@ -445,14 +445,16 @@ def test_combined_pass_weight_gradient_equals_separate(graph, monkeypatch):
     g1 = m1.grp_G.grad.clone()
     l1 += [m1.train_step(rA, rB) for _ in range(2)]
     assert not ops._WG_STASH, "the region must be closed (and its stash flushed) after the step"
-    # every ResBlock conv pair of every Python-level backward (3 eager steps; warm-up + capture in graph mode): stashed on the
-    # first visit, combined on the second
-    assert sum(seen) >= 4 * 3 and sum(seen) % (4 * 3) == 0, sum(seen)
+    # every generator conv pair except the 7x7 head (6 ResBlock convs, 4 stride-2 layers, the stem) of every Python-level backward
+    # (3 eager steps; warm-up + capture in graph mode): stashed on the first visit, combined on the second
+    assert sum(seen) >= 2 * 11 and sum(seen) % (2 * 11) == 0, sum(seen)
     scale = float(g0.abs().max())
     assert float((g0 - g1).abs().max()) <= 2e-5 * scale
-    for a, b in zip(l0, l1):
+    # first step: the same forward, so the losses agree to rounding; later steps drift apart the way the oracle itself does under a
+    # 1e-6 perturbation of its weights (scripts/oracle_sensitivity.py: percents within a few steps), so they only have to stay close
+    for i, (a, b) in enumerate(zip(l0, l1)):
         for k in a:
-            assert abs(a[k] - b[k]) <= 2e-3 * max(1.0, abs(a[k])), (k, a[k], b[k])
+            assert abs(a[k] - b[k]) <= (1e-5 if i == 0 else 4e-2) * max(1.0, abs(a[k])), (i, k, a[k], b[k])
     m0.close(); m1.close()
 
 

@@ -357,6 +357,44 @@ def test_wgrad_two_batch_launch_matches_single(swap2):
         assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("kind,cin,cout,k,st,pd,pm,hw,dtype", [("conv", 64, 128, 3, 2, 1, "zero", 32, torch.bfloat16), ("convT", 128, 64, 3, 2, 1, "zero", 16, torch.bfloat16),
+                                                            ("conv", 3, 64, 7, 1, 3, "reflect", 24, torch.bfloat16), ("conv", 64, 128, 4, 2, 1, "zero", 20, torch.float32)],
+                         ids=["down-s2", "up-convT", "stem7x7", "d4x4-f32-ragged"])
+@pytest.mark.parametrize("swap2", [0, 1])
+def test_wgrad_two_batch_launch_generic_kernel(kind, cin, cout, k, st, pd, pm, hw, dtype, swap2):
+    """uig_wgrad_partial_pair2 on the GENERIC split-K kernel (every shape but the image-row and the 7x7-head kernels'): the pixel
+    splits are divided between the two tensor pairs; against the sum of one launch per network and batch."""
+    u, ops, networks = _mods()
+    L = u.lib
+    lib = L.lib()
+    torch.manual_seed(60 + swap2 + hw)
+    layer = networks.ConvLayer(kind, cin, cout, k, st, pd, pm, dtype=dtype, device="cuda")
+    spec = layer.spec
+    xs, dys = [], []
+    for B in (5, 3):
+        x = (torch.rand(B, hw, hw, spec.cin_p, device="cuda") * 2 - 1).to(dtype)
+        Ho, Wo = spec.out_hw(hw, hw)
+        xs.append(x); dys.append((torch.randn(B, Ho, Wo, spec.cout_p, device="cuda") * 0.5).to(dtype))
+    g1, g2 = 3, 2
+    P1, Q1, Mh, Mw, Np, Hq, Wq, Cq, pmode, D0, D1 = ops._wgrad_operands(spec, xs[0], dys[0])
+    P2, Q2 = ops._wgrad_operands(spec, xs[1], dys[1])[:2]
+    dt = L.BF16 if dtype == torch.bfloat16 else L.F32
+    args = (Mh, Mw, Np, Hq, Wq, Cq, k, k, st, pd)
+    splits = int(lib.uig_wgrad_pair2_splits(5, g1, 3, g2, swap2, *args, dt))
+    assert splits >= 2
+    per = splits * Np * k * k * Cq
+    ws = torch.empty((2 * per,), device="cuda", dtype=torch.float32)
+    s = torch.cuda.current_stream().cuda_stream
+    L.check(lib.uig_wgrad_partial_pair2(P1.data_ptr(), Q1.data_ptr(), P2.data_ptr(), Q2.data_ptr(), ws.data_ptr(), 5, g1, 3, g2, swap2,
+                                        *args, pmode, splits, dt, s), "uig_wgrad_partial_pair2")
+    a2, b2 = (slice(g2, 3), slice(0, g2)) if swap2 else (slice(0, g2), slice(g2, 3))
+    for part, s1, s2 in (((ws[:per], splits), slice(0, g1), a2), ((ws[per:], splits), slice(g1, 5), b2)):
+        got = ops.conv_wgrad(spec, xs[0][s1], dys[0][s1], partial=part)
+        ref = ops.conv_wgrad(spec, xs[0][s1], dys[0][s1]) + ops.conv_wgrad(spec, xs[1][s2], dys[1][s2])
+        torch.cuda.synchronize()
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("act", ["tanh", "lrelu"])
 def test_conv_epilogue_activation(act, dtype):

@@ -21,6 +21,12 @@ struct WgradDesc {
     int group_M, splits;     // two networks in one launch (group_M > 0): pixels [0, group_M) are network 0's; gridDim.y = 2 * splits and
                              // the partial slabs are laid out [network][split]
     unsigned p_bytes, q_bytes;
+    // two RUNS of pixels per network (round 2: both generator passes of a step in one launch): splits [0, splits0) of a network
+    // walk its pixels of (P, Q) as above, splits [splits0, splits) its pixels of a second tensor pair (P2, Q2) of M2 pixels, of
+    // which [0, group_M2) are network (swap2 ? 1 : 0)'s.  A split never leaves its run, so the kernel body sees one tensor pair.
+    // splits0 == 0: one run (P2 / Q2 unused).
+    int splits0, M2, group_M2, swap2, Mper2;
+    unsigned p2_bytes, q2_bytes;
 };
 
 template <typename T> struct WgTraits;
@@ -32,7 +38,8 @@ template <> struct WgTraits<float> { static constexpr int PAD = 64; };
 // BN = 256 runs 8 waves (512 threads): the gathered Q tile is staged once for all 256 rows of the dense operand instead of
 // once per 128-row tile (48 KB instead of 64 KB of staging per 2.1 MMAC).
 template <typename T, int BN, bool FASTROW>
-__global__ __launch_bounds__((BN >= 256 ? 512 : 256), 2) void wgrad_kernel(const T* __restrict__ P, const T* __restrict__ Q,
+__global__ __launch_bounds__((BN >= 256 ? 512 : 256), 2) void wgrad_kernel(const T* __restrict__ P1, const T* __restrict__ Q1,
+                                                        const T* __restrict__ P2, const T* __restrict__ Q2,
                                                         float* __restrict__ part, const WgradDesc d) {
     constexpr int E = ElemTraits<T>::E;
     constexpr int BC = 128;
@@ -52,9 +59,15 @@ __global__ __launch_bounds__((BN >= 256 ? 512 : 256), 2) void wgrad_kernel(const
     const int n_base = (blockIdx.x % ntn) * BN, col_base = (blockIdx.x / ntn) * BC;
     const int net = d.group_M > 0 ? (int)blockIdx.y / d.splits : 0;
     const int split = d.group_M > 0 ? (int)blockIdx.y % d.splits : (int)blockIdx.y;
-    const int net_m0 = net ? d.group_M : 0, net_m1 = (d.group_M > 0 && !net) ? d.group_M : d.M;
-    const int m_begin = net_m0 + split * d.Mper;
-    const int m_end = min(net_m1, m_begin + d.Mper);
+    const bool run1 = d.splits0 > 0 && split >= d.splits0;            // block-uniform: this split walks the second tensor pair
+    const int net2 = d.swap2 ? 1 - net : net;
+    const int net_m0 = run1 ? (net2 ? d.group_M2 : 0) : (net ? d.group_M : 0);
+    const int net_m1 = run1 ? (net2 ? d.M2 : d.group_M2) : ((d.group_M > 0 && !net) ? d.group_M : d.M);
+    const int mper = run1 ? d.Mper2 : d.Mper;
+    const int m_begin = net_m0 + (run1 ? split - d.splits0 : split) * mper;
+    const int m_end = min(net_m1, m_begin + mper);
+    const T* P = run1 ? P2 : P1;
+    const T* Q = run1 ? Q2 : Q1;
     const int nk = (m_end > m_begin) ? (m_end - m_begin + BKP - 1) / BKP : 0;
 
     // fixed per-thread chunk columns
@@ -80,8 +93,8 @@ __global__ __launch_bounds__((BN >= 256 ? 512 : 256), 2) void wgrad_kernel(const
 
     u32x4_t rq[QI], rp[PI];
     // buffer descriptors: invalid rows / zero padding use an out-of-range offset (hardware returns zeros)
-    const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Q), 0, d.q_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(P), 0, d.p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Q), 0, run1 ? d.q2_bytes : d.q_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(P), 0, run1 ? d.p2_bytes : d.p_bytes, 0x00020000);
     // running pixel coordinates of the K-step being loaded: one division at the start, then incremental updates (per-K-step
     // divisions made this loop VALU-bound: ~250 VALU per 16 MFMAs).  FASTROW keeps ONE block-uniform (b0, i0, j0).
     int qj[QI], qi[QI], qb[QI];
@@ -324,7 +337,7 @@ extern "C" size_t uig_wgrad_workspace_bytes(int Np, int Cq, int kH, int kW, int 
 }
 
 template <typename T, int BN, bool FASTROW>
-static int launch_wgrad(const void* P, const void* Q, float* ws, const WgradDesc& d, int splits, hipStream_t s) {
+static int launch_wgrad(const void* P, const void* Q, float* ws, const WgradDesc& d, int splits, hipStream_t s, const void* P2 = nullptr, const void* Q2 = nullptr) {
     constexpr int PROW = BN * (int)sizeof(T) + WgTraits<T>::PAD, QROW = 128 * (int)sizeof(T) + WgTraits<T>::PAD;
     const size_t smem = 2 * (size_t)(sizeof(T) == 2 ? 64 : 32) * (size_t)(PROW + QROW);
     auto kern = wgrad_kernel<T, BN, FASTROW>;
@@ -334,7 +347,7 @@ static int launch_wgrad(const void* P, const void* Q, float* ws, const WgradDesc
         if (e != hipSuccess) return uig_set_error((int)e, "wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     }
     const int ntn = (d.Np + BN - 1) / BN, ntc = (d.ncols + 127) / 128;
-    hipLaunchKernelGGL(kern, dim3(ntn * ntc, splits * (d.group_M > 0 ? 2 : 1)), dim3(BN >= 256 ? 512 : 256), smem, s, (const T*)P, (const T*)Q, ws, d);
+    hipLaunchKernelGGL(kern, dim3(ntn * ntc, splits * (d.group_M > 0 ? 2 : 1)), dim3(BN >= 256 ? 512 : 256), smem, s, (const T*)P, (const T*)Q, (const T*)P2, (const T*)Q2, ws, d);
     UIG_LAUNCH_CHECK("uig_wgrad_partial");
     return 0;
 }
@@ -371,9 +384,10 @@ extern "C" int uig_wgrad_splits(int B, int Mh, int Mw, int Np, int Hq, int Wq, i
     return (int)std::max<long>(1, std::min<long>(std::max(target_blocks, 1) / std::max(tiles, 1), M / 128));
 }
 
+struct WgRun2 { const void* P2; const void* Q2; int B2, g2, swap2, splits0; };      // second run of the generic kernel (uig_wgrad_partial_pair2)
 static int wgrad_partial_impl(const void* P, const void* Q, float* workspace, int B, int group_images, int Mh, int Mw, int Np,
                               int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int pad_mode,
-                              int splits, int dtype, void* stream) {
+                              int splits, int dtype, void* stream, const WgRun2* r2 = nullptr) {
     UIG_CHECK_ARG(P && Q && workspace, "uig_wgrad_partial: null pointer");
     UIG_CHECK_ARG(group_images >= 0 && group_images < B, "uig_wgrad_partial: bad group_images %d of %d", group_images, B);
     UIG_CHECK_ARG(Np % 8 == 0 && Cq % 8 == 0 && Np > 0 && Cq > 0, "uig_wgrad_partial: channels must be padded to 8 (Np=%d Cq=%d)", Np, Cq);
@@ -393,28 +407,40 @@ static int wgrad_partial_impl(const void* P, const void* Q, float* workspace, in
     d.ncols = kH * kW * Cq; d.M = B * Mh * Mw;
     d.group_M = group_images * Mh * Mw; d.splits = splits;
     const int M_net = group_images > 0 ? std::max(d.group_M, d.M - d.group_M) : d.M;
-    d.Mper = ((M_net + splits - 1) / splits + 63) / 64 * 64;
     const long esz = dtype == UIG_BF16 ? 2 : 4;
     d.p_bytes = (unsigned)((long)B * Mh * Mw * Np * esz); d.q_bytes = (unsigned)((long)B * Hq * Wq * Cq * esz);
     hipStream_t s = (hipStream_t)stream;
-    if (uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype) &&
+    const void* P2 = nullptr; const void* Q2 = nullptr;
+    if (r2 != nullptr) {      // generic kernel, two runs: the first splits0 splits of a network on (P, Q), the others on (P2, Q2)
+        UIG_CHECK_ARG(group_images > 0 && r2->P2 && r2->Q2 && r2->g2 > 0 && r2->g2 < r2->B2 && r2->splits0 >= 1 && r2->splits0 < splits, "uig_wgrad_partial_pair2: bad second run");
+        UIG_CHECK_ARG((long)r2->B2 * Mh * Mw * Np * esz < (1L << 32) - 64 && (long)r2->B2 * Hq * Wq * Cq * esz < (1L << 32) - 64, "uig_wgrad_partial_pair2: tensor too large for 32-bit byte offsets");
+        P2 = r2->P2; Q2 = r2->Q2;
+        d.splits0 = r2->splits0; d.M2 = r2->B2 * Mh * Mw; d.group_M2 = r2->g2 * Mh * Mw; d.swap2 = r2->swap2;
+        d.p2_bytes = (unsigned)((long)r2->B2 * Mh * Mw * Np * esz); d.q2_bytes = (unsigned)((long)r2->B2 * Hq * Wq * Cq * esz);
+        d.Mper = ((M_net + d.splits0 - 1) / d.splits0 + 63) / 64 * 64;
+        const int M_net2 = std::max(d.group_M2, d.M2 - d.group_M2), s1 = splits - d.splits0;
+        d.Mper2 = ((M_net2 + s1 - 1) / s1 + 63) / 64 * 64;
+    } else {
+        d.Mper = ((M_net + splits - 1) / splits + 63) / 64 * 64;
+    }
+    if (r2 == nullptr && uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype) &&
         splits <= (group_images > 0 ? std::min(group_images, B - group_images) : B) * Mh)
         return uig_launch_wgrad_rows(P, Q, workspace, B, Mh, Np, Cq, pad_mode, splits, group_images, s);
-    if (uig_wgrad_head_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype) &&
+    if (r2 == nullptr && uig_wgrad_head_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype) &&
         splits <= (group_images > 0 ? std::min(group_images, B - group_images) : B) * Mh)
         return uig_launch_wgrad_head(P, Q, workspace, B, Mh, Mw, Np, pad_mode, splits, group_images, s);
     const int bkp = dtype == UIG_BF16 ? 64 : 32;
     const bool fast = (Mw % bkp) == 0;          // a K-step never leaves its image row (Mper is a multiple of bkp)
-    if (g_wgrad_bn256 && Np % 256 == 0 && fast) {       // wide dense tile (the caller halves `splits`: uig_wgrad_tile_rows)
+    if (r2 == nullptr && g_wgrad_bn256 && Np % 256 == 0 && fast) {       // wide dense tile (the caller halves `splits`: uig_wgrad_tile_rows)
         return dtype == UIG_BF16 ? launch_wgrad<bf16_t, 256, true>(P, Q, workspace, d, splits, s)
                                  : launch_wgrad<float, 256, true>(P, Q, workspace, d, splits, s);
     }
     if (dtype == UIG_BF16) {
-        if (Np <= 16) return fast ? launch_wgrad<bf16_t, 16, true>(P, Q, workspace, d, splits, s) : launch_wgrad<bf16_t, 16, false>(P, Q, workspace, d, splits, s);
-        return fast ? launch_wgrad<bf16_t, 128, true>(P, Q, workspace, d, splits, s) : launch_wgrad<bf16_t, 128, false>(P, Q, workspace, d, splits, s);
+        if (Np <= 16) return fast ? launch_wgrad<bf16_t, 16, true>(P, Q, workspace, d, splits, s, P2, Q2) : launch_wgrad<bf16_t, 16, false>(P, Q, workspace, d, splits, s, P2, Q2);
+        return fast ? launch_wgrad<bf16_t, 128, true>(P, Q, workspace, d, splits, s, P2, Q2) : launch_wgrad<bf16_t, 128, false>(P, Q, workspace, d, splits, s, P2, Q2);
     }
-    if (Np <= 16) return fast ? launch_wgrad<float, 16, true>(P, Q, workspace, d, splits, s) : launch_wgrad<float, 16, false>(P, Q, workspace, d, splits, s);
-    return fast ? launch_wgrad<float, 128, true>(P, Q, workspace, d, splits, s) : launch_wgrad<float, 128, false>(P, Q, workspace, d, splits, s);
+    if (Np <= 16) return fast ? launch_wgrad<float, 16, true>(P, Q, workspace, d, splits, s, P2, Q2) : launch_wgrad<float, 16, false>(P, Q, workspace, d, splits, s, P2, Q2);
+    return fast ? launch_wgrad<float, 128, true>(P, Q, workspace, d, splits, s, P2, Q2) : launch_wgrad<float, 128, false>(P, Q, workspace, d, splits, s, P2, Q2);
 }
 
 extern "C" int uig_wgrad_partial(const void* P, const void* Q, float* workspace, int B, int Mh, int Mw, int Np,
@@ -451,24 +477,56 @@ extern "C" int uig_wgrad_partial_pair(const void* P, const void* Q, float* works
 // two weight sets, pass 1 on (P, Q) = B1 images of which the first g1 are network 0's, pass 2 on (P2, Q2) = B2 images of which
 // the first g2 are network (swap2 ? 1 : 0)'s.  One launch instead of two: the fixed cost of a split-K launch (fill / drain, the
 // partial slabs and their reduce) is paid once - measured 147 us against 111 + 74 us for 16 + 8 images incl. the reduce.
-// Only for shapes the image-row kernel takes (uig_wgrad_pair2_splits returns 0 otherwise: run the two launches).
-// Workspace: [2][splits][Np][9*Cq] floats, reduced like uig_wgrad_partial_pair's.
+// Image-row kernel shapes: two runs of whole images per network inside the kernel's row walk.  Every other shape except the 7x7
+// head kernel's: the generic split-K kernel with the pixel splits divided between the two tensor pairs (a split never leaves its
+// pair); measured per layer pair at 16 + 8 images (scripts/bench_wgrad_combine_generic.py): down1 / up2 200 -> 169 us, down2 / up1
+// 122 -> 102 us, stem 270 -> 248 us.  uig_wgrad_pair2_splits returns 0 where the two launches must stay.
+// Workspace: [2][splits][Np][kH*kW*Cq] floats, reduced like uig_wgrad_partial_pair's.
 int uig_launch_wgrad_rows_runs(const void* P, const void* Q, const void* P2, const void* Q2, float* ws, int B1, int B2, int H, int Np, int Cq,
                                int pad_mode, int splits, const int* imgs, const int* img0, const int* sel, hipStream_t s);
+// generic kernel, two runs: S splits per network in all (the grid of uig_wgrad_pair_splits for the whole batch), divided between
+// the runs in proportion to their pixels, at least one each
+static void pair2_generic_splits(int B1, int g1, int B2, int g2, int swap2, int Mh, int Mw, int Np, int Cq, int kH, int kW, int dtype,
+                                 int* splits, int* splits0) {
+    const int bn = uig_wgrad_tile_rows(Np, Mw, dtype);
+    const int tiles = 2 * ((Np + bn - 1) / bn) * ((kH * kW * Cq + 127) / 128);
+    const long px = (long)Mh * Mw;
+    const long m1 = (long)std::min(g1, B1 - g1) * px, m2 = (long)std::min(g2, B2 - g2) * px;
+    long S = std::max<long>(2, std::min<long>(512 / std::max(tiles, 1), (m1 + m2) / 128));
+    long s0 = std::max<long>(1, std::min<long>(S - 1, (S * ((long)B1 * px) + ((long)(B1 + B2) * px) / 2) / ((long)(B1 + B2) * px)));
+    s0 = std::min<long>(s0, std::max<long>(1, m1 / 64));
+    long s1 = std::max<long>(1, std::min<long>(S - s0, std::max<long>(1, m2 / 64)));
+    (void)swap2;
+    *splits = (int)(s0 + s1); *splits0 = (int)s0;
+}
 extern "C" int uig_wgrad_pair2_splits(int B1, int g1, int B2, int g2, int swap2, int Mh, int Mw, int Np, int Hq, int Wq, int Cq,
                                       int kH, int kW, int stride, int pad, int dtype) {
     if (g1 <= 0 || g1 >= B1 || g2 <= 0 || g2 >= B2) return 0;
-    if (!uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype)) return 0;
-    const int n0 = g1 + (swap2 ? B2 - g2 : g2), n1 = (B1 - g1) + (swap2 ? g2 : B2 - g2);
     if ((long)(B1 + B2) * Mh * Mw * std::max(Np, Cq) * 2 >= (1L << 32) - 64) return 0;
-    return (int)std::max<long>(1, std::min<long>(256 / (2 * uig_wgrad_rows_tiles(Np, Cq)), (long)std::min(n0, n1) * Mh));
+    if (uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype)) {
+        const int n0 = g1 + (swap2 ? B2 - g2 : g2), n1 = (B1 - g1) + (swap2 ? g2 : B2 - g2);
+        return (int)std::max<long>(1, std::min<long>(256 / (2 * uig_wgrad_rows_tiles(Np, Cq)), (long)std::min(n0, n1) * Mh));
+    }
+    if (uig_wgrad_head_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype)) return 0;      // the 7x7 head kernel: one batch per launch
+    if (dtype != UIG_BF16 && dtype != UIG_F32) return 0;
+    int splits = 0, splits0 = 0;
+    pair2_generic_splits(B1, g1, B2, g2, swap2, Mh, Mw, Np, Cq, kH, kW, dtype, &splits, &splits0);
+    return splits;
 }
 extern "C" int uig_wgrad_partial_pair2(const void* P, const void* Q, const void* P2, const void* Q2, float* workspace,
                                        int B1, int g1, int B2, int g2, int swap2, int Mh, int Mw, int Np, int Hq, int Wq, int Cq,
                                        int kH, int kW, int stride, int pad, int pad_mode, int splits, int dtype, void* stream) {
     UIG_CHECK_ARG(P && Q && P2 && Q2 && workspace, "uig_wgrad_partial_pair2: null pointer");
-    UIG_CHECK_ARG(uig_wgrad_pair2_splits(B1, g1, B2, g2, swap2, Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype) > 0,
-                  "uig_wgrad_partial_pair2: shape not supported by the image-row kernel (query uig_wgrad_pair2_splits)");
+    const int want = uig_wgrad_pair2_splits(B1, g1, B2, g2, swap2, Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype);
+    UIG_CHECK_ARG(want > 0, "uig_wgrad_partial_pair2: shape not supported (query uig_wgrad_pair2_splits)");
+    if (!uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype)) {
+        // generic split-K kernel: the split between the two runs is fixed by the shape, so `splits` must be the queried value
+        UIG_CHECK_ARG(splits == want, "uig_wgrad_partial_pair2: splits %d != uig_wgrad_pair2_splits() = %d", splits, want);
+        int s_all = 0, s0 = 0;
+        pair2_generic_splits(B1, g1, B2, g2, swap2, Mh, Mw, Np, Cq, kH, kW, dtype, &s_all, &s0);
+        const WgRun2 r2{P2, Q2, B2, g2, swap2, s0};
+        return wgrad_partial_impl(P, Q, workspace, B1, g1, Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, pad_mode, splits, dtype, stream, &r2);
+    }
     const int n0 = g1 + (swap2 ? B2 - g2 : g2), n1 = (B1 - g1) + (swap2 ? g2 : B2 - g2);
     UIG_CHECK_ARG(splits >= 1 && splits <= std::min(n0, n1) * Mh, "uig_wgrad_partial_pair2: bad splits %d", splits);
     // network 0: pass-1 images [0, g1), then pass-2's share; network 1: pass-1 images [g1, B1), then pass-2's share

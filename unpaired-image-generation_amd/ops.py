@@ -703,7 +703,7 @@ def _conv_backward(ctx, dy, layers, group):
         side.wait_stream(main)
     with (torch.cuda.stream(side) if par else contextlib.nullcontext()):
         stash = _WG_STASH.get(torch.device(dy.device).index)
-        combined = stash is not None and npar == 2 and all(need_w) and all(need_b) and fused_all and PAIR_WGRAD and spec.kind == "conv" \
+        combined = stash is not None and npar == 2 and all(need_w) and all(need_b) and fused_all and PAIR_WGRAD \
             and _combined_wgrad(layers, spec, x, dy, group, colsum, stash)
         pparts = None
         if combined:
