@@ -358,7 +358,7 @@ extern "C" void uig_debug_set_wgrad_wide(int on) { g_wgrad_bn256 = on; }
 extern "C" int uig_wgrad_tile_rows(int Np, int Mw, int dtype) {
     const int bkp = dtype == UIG_BF16 ? 64 : 32;
     if (g_wgrad_bn256 && Np % 256 == 0 && (Mw % bkp) == 0) return 256;
-    return Np <= 16 ? 16 : 128;
+    return Np <= 16 ? 16 : (Np <= 64 ? 64 : 128);      // 64: the 7x7 stem and the PatchGAN's first layer (64 output channels): half the dense tile of the 128-row form was padding
 }
 
 // wgrad_rows.hip: stride-1 3x3 "same" convs on 64-pixel rows, bf16
@@ -437,9 +437,11 @@ static int wgrad_partial_impl(const void* P, const void* Q, float* workspace, in
     }
     if (dtype == UIG_BF16) {
         if (Np <= 16) return fast ? launch_wgrad<bf16_t, 16, true>(P, Q, workspace, d, splits, s, P2, Q2) : launch_wgrad<bf16_t, 16, false>(P, Q, workspace, d, splits, s, P2, Q2);
+        if (Np <= 64) return fast ? launch_wgrad<bf16_t, 64, true>(P, Q, workspace, d, splits, s, P2, Q2) : launch_wgrad<bf16_t, 64, false>(P, Q, workspace, d, splits, s, P2, Q2);
         return fast ? launch_wgrad<bf16_t, 128, true>(P, Q, workspace, d, splits, s, P2, Q2) : launch_wgrad<bf16_t, 128, false>(P, Q, workspace, d, splits, s, P2, Q2);
     }
     if (Np <= 16) return fast ? launch_wgrad<float, 16, true>(P, Q, workspace, d, splits, s, P2, Q2) : launch_wgrad<float, 16, false>(P, Q, workspace, d, splits, s, P2, Q2);
+    if (Np <= 64) return fast ? launch_wgrad<float, 64, true>(P, Q, workspace, d, splits, s, P2, Q2) : launch_wgrad<float, 64, false>(P, Q, workspace, d, splits, s, P2, Q2);
     return fast ? launch_wgrad<float, 128, true>(P, Q, workspace, d, splits, s, P2, Q2) : launch_wgrad<float, 128, false>(P, Q, workspace, d, splits, s, P2, Q2);
 }
 
