@@ -50,7 +50,9 @@ void uig_debug_set_strip(int on);
 /* tuning hook of the persistent strip kernel: dm = DMA issue placement (0 top of the K-step, 1 spread between MFMA groups),
  * grid = persistent grid size (0 = one block per CU) */
 void uig_debug_set_strip_pk(int dm, int grid);
-/* tuning / test hook: 1 (default) = uig_reflect3x3_dgrad_mirror_applicable may say 1; 0 = it never does (A/B against the border GEMM) */
+/* tuning / test hook: 1 (default) = uig_reflect3x3_dgrad_mirror_applicable may say 1; 0 = it never does (A/B against the border GEMM);
+ * 3 / 5 / 7 = diagnostic timing builds of the mirror kernel WITHOUT its per-chunk / first-chunk / any mirror sums (wrong results:
+ * scripts/bench_dgrad_mirror.py and scripts/stamp_strip_pk.py only) */
 void uig_debug_set_mirror(int on);
 /* tuning / test hook: 1 (default) = 7x7 stride-1 convs with <= 16 output channels use the row-strip kernel */
 void uig_debug_set_rowstrip(int on);

@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256, 2) void conv_cin8_kernel(const bf16_t* __restr
             unsigned char* scr = sc + wave * 1024;
             const int c = lane & 7, r0 = lane >> 3;
             bf16_t* yrow = y + (((long)img * d.Ho + ho) * d.Wo + wo0 + wave * 32) * d.ldc;
+            with_act(d.act, d.slope, [&](auto actf) {       // one activation branch per output row, not one switch per element
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
                 const int b = ps >> 1;
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv_cin8_kernel(const bf16_t* __restr
                     for (int a = 0; a < 4; ++a) {
                         float v[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[a][b][e] + bv[a * 4 + e], d.act, d.slope);
+                        for (int e = 0; e < 4; ++e) v[e] = actf(acc[a][b][e] + bv[a * 4 + e]);
                         u32x2_t pk;
                         pk[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
                         pk[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv_cin8_kernel(const bf16_t* __restr
                     }
                 }
             }
+            });
         }
     }
 }

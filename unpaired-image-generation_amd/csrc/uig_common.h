@@ -64,6 +64,16 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     }
 }
 
+// ONE branch on the (launch-constant) activation around a whole epilogue loop: body(actf) is instantiated per activation.  A
+// switch per element carries an inlined tanhf body per element to jump over (see store_tile_via_lds).
+template <typename Body>
+__device__ __forceinline__ void with_act(int act, float slope, Body&& body) {
+    if (act == UIG_ACT_NONE) body([](float v) { return v; });
+    else if (act == UIG_ACT_RELU) body([](float v) { return v > 0.f ? v : 0.f; });
+    else if (act == UIG_ACT_LRELU) body([slope](float v) { return v > 0.f ? v : v * slope; });
+    else body([](float v) { return tanhf(v); });
+}
+
 __device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
 // wave64 all-reduce sum via DPP-free shuffles (width 64)
@@ -123,10 +133,7 @@ __device__ __forceinline__ void store_tile_via_lds(const f32x4_t (&acc)[NT][MT],
             }
         }
     };
-    if (act == UIG_ACT_NONE) to_lds([](float v) { return v; });
-    else if (act == UIG_ACT_RELU) to_lds([](float v) { return v > 0.f ? v : 0.f; });
-    else if (act == UIG_ACT_LRELU) to_lds([slope](float v) { return v > 0.f ? v : v * slope; });
-    else to_lds([](float v) { return tanhf(v); });
+    with_act(act, slope, to_lds);
     // The tile is written as 8-byte / f32x4 vectors and read back as u32x4: different vector types, which type-based alias
     // analysis may treat as non-aliasing (seen in conv_cin8.hip: reads scheduled above the writes).  Compiler barrier.
     asm volatile("" ::: "memory");
