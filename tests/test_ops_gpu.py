@@ -271,6 +271,25 @@ def test_wgrad_head_kernel_matches_generic(pm, H, W):
         assert float((g_ - r_).abs().max()) <= 2e-5 * scale, f"head kernel vs generic: {float((g_ - r_).abs().max())} of {scale}"
 
 
+def test_wgrad_special_kernels_vs_oracle_at_real_widths():
+    """The two specialised weight-gradient kernels against the ORACLE (stock torch autograd on bf16-rounded operands), not only
+    against the generic kernel, at the row widths of the 256x256 benchmark: the 7x7 head kernel (64 -> 3 channels, 256-pixel rows,
+    reflection pad 3) and the image-row kernel of the ResBlock convs (256 -> 256, 64-pixel rows, reflection pad 1); the bf16
+    tolerance of every op test (1.6e-2 of the reference's scale)."""
+    u, ops, networks = _mods()
+    dt = torch.bfloat16
+    for cin, cout, k, pad, H, W, B in ((64, 3, 7, 3, 12, 256, 2), (256, 256, 3, 1, 64, 64, 2)):
+        torch.manual_seed(70 + k)
+        layer = networks.ConvLayer("conv", cin, cout, k, 1, pad, "reflect", dtype=dt, device="cuda")
+        x = torch.rand(B, cin, H, W) * 2 - 1
+        dy = torch.randn(B, cout, H, W) * 0.5
+        w = torch.zeros(cout, cin, k, k, requires_grad=True)
+        F.conv2d(F.pad(_bf(x), (pad,) * 4, mode="reflect"), w).backward(_bf(dy))
+        got = ops.conv_wgrad(layer.spec, ops.to_nhwc(x.cuda(), dt), ops.to_nhwc(dy.cuda(), dt, layer.spec.cout_p)).cpu()
+        assert got.shape == w.grad.shape
+        assert (got - w.grad).abs().max() <= _tol(dt, w.grad), f"{k}x{k}: {(got - w.grad).abs().max()} of {w.grad.abs().max()}"
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_multi_packer_matches_per_layer_pack(dtype):
     """one-launch tile-transposing weight packer (all layers of a generator and a discriminator) against the per-layer
