@@ -377,12 +377,14 @@ def test_wgrad_two_batch_launch_matches_single(swap2):
 
 
 @pytest.mark.parametrize("kind,cin,cout,k,st,pd,pm,hw,dtype", [("conv", 64, 128, 3, 2, 1, "zero", 32, torch.bfloat16), ("convT", 128, 64, 3, 2, 1, "zero", 16, torch.bfloat16),
-                                                            ("conv", 3, 64, 7, 1, 3, "reflect", 24, torch.bfloat16), ("conv", 64, 128, 4, 2, 1, "zero", 20, torch.float32)],
-                         ids=["down-s2", "up-convT", "stem7x7", "d4x4-f32-ragged"])
+                                                            ("conv", 3, 64, 7, 1, 3, "reflect", 24, torch.bfloat16), ("conv", 64, 128, 4, 2, 1, "zero", 20, torch.float32),
+                                                            ("conv", 64, 3, 7, 1, 3, "reflect", 24, torch.bfloat16)],
+                         ids=["down-s2", "up-convT", "stem7x7", "d4x4-f32-ragged", "head7x7-all-rows-kernel"])
 @pytest.mark.parametrize("swap2", [0, 1])
 def test_wgrad_two_batch_launch_generic_kernel(kind, cin, cout, k, st, pd, pm, hw, dtype, swap2):
-    """uig_wgrad_partial_pair2 on the GENERIC split-K kernel (every shape but the image-row and the 7x7-head kernels'): the pixel
-    splits are divided between the two tensor pairs; against the sum of one launch per network and batch."""
+    """uig_wgrad_partial_pair2 on the GENERIC split-K kernel (the pixel splits are divided between the two tensor pairs) and on the
+    all-rows 7x7 head kernel (an image is a block's unit: the second pair is a pointer select); against the sum of one launch per
+    network and batch."""
     u, ops, networks = _mods()
     L = u.lib
     lib = L.lib()

@@ -368,6 +368,10 @@ int uig_launch_wgrad_rows(const void* P, const void* Q, float* ws, int B, int H,
 // wgrad_head.hip: 7x7 stride-1 pad-3 convs with 64 input and <= 8 (padded) output channels, bf16
 bool uig_wgrad_head_applicable(int Mh, int Mw, int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int dtype);
 int uig_launch_wgrad_head(const void* P, const void* Q, float* ws, int B, int H, int W, int Np, int pad_mode, int splits, int group_images, hipStream_t s);
+int uig_wgrad_head_splits(int B, int group_images, int H);
+int uig_wgrad_head_splits2(int B1, int g1, int B2, int g2, int swap2, int H);
+int uig_launch_wgrad_head_runs(const void* P, const void* Q, const void* P2, const void* Q2, float* ws, int B1, int g1, int B2, int g2, int swap2,
+                               int H, int W, int Np, int pad_mode, int splits, hipStream_t s);
 
 // number of pixel-range splits (= fp32 partial slabs) uig_wgrad_partial should run with for this shape: the kernel it will
 // dispatch to decides (row kernel: one 8-wave block per CU; generic kernel: `target_blocks` 4-wave blocks, two per CU)
@@ -377,7 +381,7 @@ extern "C" int uig_wgrad_splits(int B, int Mh, int Mw, int Np, int Hq, int Wq, i
     if (uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype))
         return (int)std::max<long>(1, std::min<long>(256 / uig_wgrad_rows_tiles(Np, Cq), (long)B * Mh));
     if (uig_wgrad_head_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype))
-        return (int)std::max<long>(1, std::min<long>(256 / 7, (long)B * Mh));
+        return uig_wgrad_head_splits(B, 0, Mh);
     const int bn = uig_wgrad_tile_rows(Np, Mw, dtype);
     const int tiles = ((Np + bn - 1) / bn) * ((kH * kW * Cq + 127) / 128);
     if (bn >= 256) return (int)std::max<long>(1, std::min<long>(256 / tiles, M / 128));
@@ -462,7 +466,7 @@ extern "C" int uig_wgrad_pair_splits(int B, int group_images, int Mh, int Mw, in
     if (uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype))
         return (int)std::max<long>(1, std::min<long>(256 / (2 * uig_wgrad_rows_tiles(Np, Cq)), (long)gmin * Mh));
     if (uig_wgrad_head_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype))
-        return (int)std::max<long>(1, std::min<long>(256 / 14, (long)gmin * Mh));
+        return uig_wgrad_head_splits(B, group_images, Mh);
     const int bn = uig_wgrad_tile_rows(Np, Mw, dtype);
     const int tiles = 2 * ((Np + bn - 1) / bn) * ((kH * kW * Cq + 127) / 128);
     const long M_net = (long)gmin * Mh * Mw;
@@ -509,7 +513,8 @@ extern "C" int uig_wgrad_pair2_splits(int B1, int g1, int B2, int g2, int swap2,
         const int n0 = g1 + (swap2 ? B2 - g2 : g2), n1 = (B1 - g1) + (swap2 ? g2 : B2 - g2);
         return (int)std::max<long>(1, std::min<long>(256 / (2 * uig_wgrad_rows_tiles(Np, Cq)), (long)std::min(n0, n1) * Mh));
     }
-    if (uig_wgrad_head_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype)) return 0;      // the 7x7 head kernel: one batch per launch
+    if (uig_wgrad_head_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype))
+        return uig_wgrad_head_splits2(B1, g1, B2, g2, swap2, Mh);      // the all-rows 7x7 head kernel: an image is a block's unit, so the second pair is a pointer select
     if (dtype != UIG_BF16 && dtype != UIG_F32) return 0;
     int splits = 0, splits0 = 0;
     pair2_generic_splits(B1, g1, B2, g2, swap2, Mh, Mw, Np, Cq, kH, kW, dtype, &splits, &splits0);
@@ -521,6 +526,10 @@ extern "C" int uig_wgrad_partial_pair2(const void* P, const void* Q, const void*
     UIG_CHECK_ARG(P && Q && P2 && Q2 && workspace, "uig_wgrad_partial_pair2: null pointer");
     const int want = uig_wgrad_pair2_splits(B1, g1, B2, g2, swap2, Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype);
     UIG_CHECK_ARG(want > 0, "uig_wgrad_partial_pair2: shape not supported (query uig_wgrad_pair2_splits)");
+    if (uig_wgrad_head_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype)) {
+        UIG_CHECK_ARG(splits == want, "uig_wgrad_partial_pair2: splits %d != uig_wgrad_pair2_splits() = %d", splits, want);
+        return uig_launch_wgrad_head_runs(P, Q, P2, Q2, workspace, B1, g1, B2, g2, swap2, Mh, Mw, Np, pad_mode, splits, (hipStream_t)stream);
+    }
     if (!uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype)) {
         // generic split-K kernel: the split between the two runs is fixed by the shape, so `splits` must be the queried value
         UIG_CHECK_ARG(splits == want, "uig_wgrad_partial_pair2: splits %d != uig_wgrad_pair2_splits() = %d", splits, want);

@@ -24,6 +24,11 @@ struct WgHeadDesc {
     int rows_total, splits;
     int group_rows;          // two networks in one launch (see wgrad_rows.hip); 0 = one
     unsigned p_bytes, q_bytes;
+    int imgs_max, chunks;    // all-kernel-rows form (wgrad_head7all_kernel): splits = imgs_max * chunks, split = image-in-network * chunks + chunk
+    // images of network n: n1[n] images of (P, Q) from image img1[n], then n2[n] images of a second tensor pair (P2, Q2) from image
+    // img2[n] (both generator passes of a step in one launch; n2 = 0: one pair)
+    int n1[2], img1[2], n2[2], img2[2];
+    unsigned p2_bytes, q2_bytes;
 };
 
 namespace {
@@ -177,12 +182,231 @@ __global__ __launch_bounds__(256, 1) void wgrad_head7_kernel(const bf16_t* __res
     }
 }
 
-static int g_wgrad_head = 1;    // A/B and parity hook
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 2: ALL SEVEN kernel rows in one block.  The form above gives every kernel row kh its own block, so an input row is
+// pulled through LDS seven times (L2 serves six of them, but the L2 -> LDS fill is what the kernel is bound by: 940 MB per
+// 16-image launch, 225 us).  Here a block walks a chunk of the PADDED rows Rp of one image, stages input row reflect(Rp) ONCE
+// and uses it for the seven (output row, kh) pairs it belongs to, i = Rp + 3 - kh: the dY rows live in an LDS ring
+// (nine slots: seven live rows + the two in flight; one new 4-KB row per step), and the shifted-dY operand S[r][kw*8 + co] = dY[i][r - kw][co] is not materialised any more -
+// the transposing read takes a per-lane address, so lane (pixel r, column group of tap kw) reads dY pixel r - kw directly
+// (16-byte pixels, zero margins of 8 pixels on both sides of a ring row; tap 7 and invalid output rows read a zero row).
+// 28 accumulator tiles per wave (7 kh x 4 column tiles), 252 MFMAs and 522 transposing reads per wave and step against one
+// 36-KB row of DMA: the fill traffic drops from 7x to (rows + 6) / rows of the input.
+// Blocks: (network, image of the network, chunk of its H + 6 padded rows); partial slabs [network][image * chunks + chunk].
+namespace {
+constexpr int WA_DYB = (8 + WH_ROWS + 8) * 16;         // one dY ring row: 8 zero pixels | up to 288 pixel slots | 8 zero pixels
+constexpr int WA_RING = 9;                             // 7 live rows i in [Rp - 3, Rp + 3] + the rows of the next two steps in flight
+constexpr int WA_DY0 = WH_NST * WH_XT, WA_ZERO = WA_DY0 + WA_RING * WA_DYB, WA_SMEM = WA_ZERO + WA_DYB;
+}
+
+__global__ __launch_bounds__(256, 1) void wgrad_head7all_kernel(const bf16_t* __restrict__ P1, const bf16_t* __restrict__ Q1,
+                                                                  const bf16_t* __restrict__ P2, const bf16_t* __restrict__ Q2,
+                                                                  float* __restrict__ part, const WgHeadDesc d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [X stage 0..2][dY ring 0..8][zero row]
+    typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nets = d.group_rows > 0 ? 2 : 1;
+    const int bid = blockIdx.x;
+    const int chunk = bid % d.chunks, t0 = bid / d.chunks, img_l = t0 % d.imgs_max, net = t0 / d.imgs_max;
+    const int n_img = d.n1[net] + d.n2[net];
+    const bool second = img_l >= d.n1[net];                         // block-uniform: this image lives in the second tensor pair
+    const int img = second ? d.img2[net] + img_l - d.n1[net] : d.img1[net] + img_l;
+    const bf16_t* P = second ? P2 : P1;
+    const bf16_t* Q = second ? Q2 : Q1;
+    (void)nets;
+    const bool refl = d.pad_mode == UIG_PAD_REFLECT;
+    const int W = d.W, H = d.H;
+    // padded rows this block walks: reflection [-3, H + 3), zero padding [0, H) (rows outside contribute nothing)
+    const int lo = refl ? -3 : 0, tp = refl ? H + 6 : H;
+    const int rp0 = lo + (int)((long)chunk * tp / d.chunks), rp1 = lo + (int)((long)(chunk + 1) * tp / d.chunks);
+    const int nk = img_l < n_img ? rp1 - rp0 : 0;
+
+    // zero margins of the ring rows and the zero row (DMAs only ever write pixel slots [8, 8 + 256))
+    for (int i = tid; i < (WA_RING + 1) * (WA_DYB / 16); i += 256) {
+        const int row = i / (WA_DYB / 16), c = i % (WA_DYB / 16);
+        if (row == WA_RING || c < 8 || c >= 8 + 256) *reinterpret_cast<u32x4_t*>(smem + WA_DY0 + row * WA_DYB + c * 16) = u32x4_t{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(P), 0, second ? d.p2_bytes : d.p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Q), 0, second ? d.q2_bytes : d.q_bytes, 0x00020000);
+    unsigned xoff[9];                                  // per piece: byte offset of this lane's source chunk inside the input row
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int r = 8 * (wave + 4 * i) + (lane >> 3);                // LDS row = padded pixel index; pixel column = r - 3
+        const int c = r - 3;
+        const bool inb = (unsigned)c < (unsigned)W;
+        const bool ok = r < W + 6 && (refl || inb);
+        const int cs = refl ? reflect_idx(c, W) : c;
+        const int chk = (lane & 7) ^ (((r >> 1) & 3) << 1);           // 16-byte chunk swizzle (conflict-free transposing reads)
+        xoff[i] = ok ? (unsigned)((cs * WH_CI + chk * 8) * 2) : 0xFFFFFFFFu;
+    }
+    const unsigned yoff = (wave * 64 + lane) < W ? (unsigned)((wave * 64 + lane) * d.Np * 2) : 0xFFFFFFFFu;   // Np == 8: 16 B per pixel
+    auto issue_dy = [&](int i) {                                       // dY row i of this image -> ring slot i mod 9 (zeros if outside the image)
+        const bool valid = (unsigned)i < (unsigned)H;
+        const int sP = __builtin_amdgcn_readfirstlane((int)((unsigned)(img * H + (valid ? i : 0)) * (unsigned)W * (unsigned)(d.Np * 2)));
+        lds_ptr_t dst = (lds_ptr_t)smem + WA_DY0 + ((i + 9 * 64) % WA_RING) * WA_DYB + (8 + 64 * wave) * 16;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (__attribute__((address_space(3))) void*)dst, 16, (int)(valid ? yoff : 0xFFFFFFFFu), sP, 0, 0);
+    };
+    auto issue = [&](int k) {                                          // step k: input row reflect(rp0 + k) -> stage k % 3, dY row rp0 + k + 3
+        const int rp = rp0 + k;
+        const int hr = refl ? reflect_idx(rp, H) : rp;
+        const int sQ = __builtin_amdgcn_readfirstlane((int)((unsigned)(img * H + hr) * (unsigned)W * (unsigned)(WH_CI * 2)));
+        lds_ptr_t dst = (lds_ptr_t)smem + (k % WH_NST) * WH_XT;
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(dst + (wave + 4 * i) * 1024), 16, (int)xoff[i], sQ, 0, 0);
+        issue_dy(rp + 3);
+    };
+
+    // ---- fragment addressing: wave w owns input channels 16w..16w+15; four 16-column tiles (tile t = taps kw 2t, 2t+1)
+    const int l16 = lane & 15, g = lane >> 4, qq = l16 >> 2, pp = l16 & 3;
+    const int k0 = 4 * g + qq;
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+    const unsigned swz = (unsigned)(((k0 >> 1) & 3) << 1);
+    const unsigned aoff = (unsigned)(k0 * 128 + (((wave * 2 + (pp >> 1)) ^ swz) << 4) + (pp & 1) * 8);
+    unsigned boff[4];                                                  // inside a ring row: dY pixel r - kw of LDS row r = k0 (+16, +32 kk)
+    bool bz[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int kw = 2 * t + (pp >> 1);
+        bz[t] = kw >= 7;
+        boff[t] = (unsigned)((8 + k0 - (bz[t] ? 0 : kw)) * 16 + (pp & 1) * 8);
+    }
+    auto tr_read = [&](unsigned addr, auto off) -> bf16x4_t {
+        u32x2_t r;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(decltype(off)::value));
+        return __builtin_bit_cast(bf16x4_t, r);
+    };
+    struct BF { bf16x8_t b[4]; };
+    auto read_b = [&](BF& f, unsigned row_base, auto kkc) {            // 8 transposing reads: the four column tiles of one (kh, k-group)
+        constexpr int o = decltype(kkc)::value * 32 * 16;
+        const unsigned zb = lds0 + (unsigned)WA_ZERO;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const unsigned a = (bz[t] ? zb : row_base) + boff[t];
+            const bf16x4_t lo = tr_read(a, std::integral_constant<int, o>{}), hi = tr_read(a, std::integral_constant<int, o + 16 * 16>{});
+            f.b[t] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+    };
+
+    f32x4_t acc[7][4];
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[kh][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) {
+#pragma unroll
+        for (int i = -3; i < 3; ++i) issue_dy(rp0 + i);                // the six rows the first step needs besides its own new one
+        issue(0);
+        if (nk > 1) issue(1);
+    }
+    for (int ks = 0; ks < nk; ++ks) {
+        if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");     // step ks landed; the 10 DMAs of step ks+1 may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // step ks complete for every wave; everyone is done with step ks-1's stage and ring slot
+        if (ks + 2 < nk) issue(ks + 2);
+        const int rp = rp0 + ks;
+        unsigned rowb[7];                                   // ring row (or the zero row) of output row i = rp + 3 - kh
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+            const int i = rp + 3 - kh;
+            rowb[kh] = lds0 + (unsigned)(((unsigned)i < (unsigned)H) ? WA_DY0 + (i % WA_RING) * WA_DYB : WA_ZERO);
+        }
+        const unsigned sa = lds0 + (unsigned)((ks % WH_NST) * WH_XT) + aoff;
+        auto kgroup = [&](auto kkc) {
+            constexpr int o = decltype(kkc)::value * 32 * 128;
+            const bf16x4_t alo = tr_read(sa, std::integral_constant<int, o>{}), ahi = tr_read(sa, std::integral_constant<int, o + 16 * 128>{});
+            bf16x8_t a = bf16x8_t{alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+            BF f0, f1;
+            auto ready8 = [&](BF& f) { asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a), "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.b[2]), "+v"(f.b[3])); };
+            auto ready0 = [&](BF& f) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.b[2]), "+v"(f.b[3])); };
+            auto mma = [&](BF& f, int kh) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[kh][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, f.b[t], acc[kh][t], 0, 0, 0);
+            };
+            read_b(f0, rowb[0], kkc);
+            read_b(f1, rowb[1], kkc); ready8(f0); mma(f0, 0);
+            read_b(f0, rowb[2], kkc); ready8(f1); mma(f1, 1);
+            read_b(f1, rowb[3], kkc); ready8(f0); mma(f0, 2);
+            read_b(f0, rowb[4], kkc); ready8(f1); mma(f1, 3);
+            read_b(f1, rowb[5], kkc); ready8(f0); mma(f0, 4);
+            read_b(f0, rowb[6], kkc); ready8(f1); mma(f1, 5);
+            ready0(f0); mma(f0, 6);
+        };
+        kgroup(std::integral_constant<int, 0>{}); kgroup(std::integral_constant<int, 1>{}); kgroup(std::integral_constant<int, 2>{});
+        kgroup(std::integral_constant<int, 3>{}); kgroup(std::integral_constant<int, 4>{}); kgroup(std::integral_constant<int, 5>{});
+        kgroup(std::integral_constant<int, 6>{}); kgroup(std::integral_constant<int, 7>{}); kgroup(std::integral_constant<int, 8>{});
+    }
+
+    // D[ci][col]: lane holds column l16 of tile t (col = 16 t + l16 = kw * 8 + co), rows ci = 16 wave + 4g .. +3
+    float* out = part + ((long)net * d.splits + (long)img_l * d.chunks + chunk) * d.Np * d.ncols;
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int col = 16 * t + l16, kw = col >> 3, co = col & 7;
+            if (kw < 7) *reinterpret_cast<f32x4_t*>(out + (long)co * d.ncols + (kh * 7 + kw) * WH_CI + wave * 16 + 4 * g) = acc[kh][t];
+        }
+}
+
+static int g_wgrad_head = 1;    // A/B and parity hook: 1 = all seven kernel rows per block (round 2), 2 = one kernel row per block (round 1), 0 = generic kernel
 extern "C" void uig_debug_set_wgrad_head(int on) { g_wgrad_head = on; }
+
+// splits (= partial slabs per network) the head kernel in force wants: all-rows form: (images of the larger network) x chunks of
+// padded rows, the grid sized for ~256 blocks; per-row form: 256 / 7 (or 14 when paired)
+static int head_all_splits(int nets, int imgs_max, int H) {
+    const int chunks = std::max(1, std::min(256 / (nets * imgs_max), (H + 6) / 4));
+    return imgs_max * chunks;
+}
+int uig_wgrad_head_splits(int B, int group_images, int H) {
+    const int nets = group_images > 0 ? 2 : 1;
+    const int imgs_max = group_images > 0 ? std::max(group_images, B - group_images) : B;
+    const int gmin = group_images > 0 ? std::min(group_images, B - group_images) : B;
+    if (g_wgrad_head == 2) return (int)std::max<long>(1, std::min<long>(256 / (7 * nets), (long)gmin * H));
+    return head_all_splits(nets, imgs_max, H);
+}
+// two tensor pairs (uig_wgrad_partial_pair2): 0 if the kernel in force cannot take them
+int uig_wgrad_head_splits2(int B1, int g1, int B2, int g2, int swap2, int H) {
+    if (g_wgrad_head != 1) return 0;
+    const int a = g1 + (swap2 ? B2 - g2 : g2), b = (B1 - g1) + (swap2 ? g2 : B2 - g2);
+    return head_all_splits(2, std::max(a, b), H);
+}
 
 bool uig_wgrad_head_applicable(int Mh, int Mw, int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int dtype) {
     return g_wgrad_head && dtype == UIG_BF16 && kH == 7 && kW == 7 && stride == 1 && pad == 3 && Mh == Hq && Mw == Wq &&
            Mw >= 8 && Mw <= WH_MAXW && Hq >= 4 && Np == 8 && Cq == WH_CI;
+}
+
+static int launch_head_all(const void* P, const void* Q, const void* P2, const void* Q2, float* ws, WgHeadDesc d, int splits, hipStream_t s) {
+    const int nets = d.n1[1] + d.n2[1] > 0 ? 2 : 1;
+    const int imgs_max = std::max(d.n1[0] + d.n2[0], d.n1[1] + d.n2[1]);
+    if (imgs_max <= 0 || splits % imgs_max != 0)
+        return uig_set_error(-1, "wgrad(head): splits %d is not images %d x chunks (use uig_wgrad_splits / uig_wgrad_pair_splits / uig_wgrad_pair2_splits)", splits, imgs_max);
+    d.imgs_max = imgs_max; d.chunks = splits / imgs_max; d.splits = splits;
+    static SmemAttrOnce attr_all;
+    hipError_t e = attr_all.ensure(reinterpret_cast<const void*>(wgrad_head7all_kernel), (size_t)WA_SMEM);
+    if (e != hipSuccess) return uig_set_error((int)e, "wgrad(head): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(wgrad_head7all_kernel, dim3(nets * splits), dim3(256), (size_t)WA_SMEM, s, (const bf16_t*)P, (const bf16_t*)Q,
+                       (const bf16_t*)(P2 ? P2 : P), (const bf16_t*)(Q2 ? Q2 : Q), ws, d);
+    UIG_LAUNCH_CHECK("uig_wgrad_partial(head, all rows)");
+    return 0;
+}
+
+// both generator passes in one launch: network 0 = images [0, g1) of (P, Q) + its share of (P2, Q2), network 1 the rest (see wgrad.hip)
+int uig_launch_wgrad_head_runs(const void* P, const void* Q, const void* P2, const void* Q2, float* ws, int B1, int g1, int B2, int g2, int swap2,
+                               int H, int W, int Np, int pad_mode, int splits, hipStream_t s) {
+    WgHeadDesc d{};
+    d.B = B1; d.H = H; d.W = W; d.Np = Np; d.pad_mode = pad_mode; d.ncols = 49 * WH_CI; d.rows_total = B1 * H; d.group_rows = g1 * H;
+    d.p_bytes = (unsigned)((long)B1 * H * W * Np * 2); d.q_bytes = (unsigned)((long)B1 * H * W * WH_CI * 2);
+    d.p2_bytes = (unsigned)((long)B2 * H * W * Np * 2); d.q2_bytes = (unsigned)((long)B2 * H * W * WH_CI * 2);
+    d.n1[0] = g1; d.img1[0] = 0; d.n1[1] = B1 - g1; d.img1[1] = g1;
+    d.n2[0] = swap2 ? B2 - g2 : g2; d.img2[0] = swap2 ? g2 : 0;
+    d.n2[1] = swap2 ? g2 : B2 - g2; d.img2[1] = swap2 ? 0 : g2;
+    return launch_head_all(P, Q, P2, Q2, ws, d, splits, s);
 }
 
 int uig_launch_wgrad_head(const void* P, const void* Q, float* ws, int B, int H, int W, int Np, int pad_mode, int splits,
@@ -191,6 +415,11 @@ int uig_launch_wgrad_head(const void* P, const void* Q, float* ws, int B, int H,
     d.B = B; d.H = H; d.W = W; d.Np = Np; d.pad_mode = pad_mode; d.ncols = 49 * WH_CI; d.rows_total = B * H;
     d.splits = splits; d.group_rows = group_images * H;
     d.p_bytes = (unsigned)((long)B * H * W * Np * 2); d.q_bytes = (unsigned)((long)B * H * W * WH_CI * 2);
+    if (g_wgrad_head != 2) {      // all seven kernel rows per block
+        if (group_images > 0) { d.n1[0] = group_images; d.img1[0] = 0; d.n1[1] = B - group_images; d.img1[1] = group_images; }
+        else { d.n1[0] = B; d.img1[0] = 0; }
+        return launch_head_all(P, Q, nullptr, nullptr, ws, d, splits, s);
+    }
     const size_t smem = (size_t)WH_NST * WH_STAGE + WH_S;
     static SmemAttrOnce attr_once;
     {
