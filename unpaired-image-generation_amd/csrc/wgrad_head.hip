@@ -195,19 +195,33 @@ __global__ __launch_bounds__(256, 1) void wgrad_head7_kernel(const bf16_t* __res
 // 36-KB row of DMA: the fill traffic drops from 7x to (rows + 6) / rows of the input.
 // Blocks: (network, image of the network, chunk of its H + 6 padded rows); partial slabs [network][image * chunks + chunk].
 namespace {
-constexpr int WA_DYB = (8 + WH_ROWS + 8) * 16;         // one dY ring row: 8 zero pixels | up to 288 pixel slots | 8 zero pixels
 constexpr int WA_RING = 9;                             // 7 live rows i in [Rp - 3, Rp + 3] + the rows of the next two steps in flight
-constexpr int WA_DY0 = WH_NST * WH_XT, WA_ZERO = WA_DY0 + WA_RING * WA_DYB, WA_SMEM = WA_ZERO + WA_DYB;
+// STEM = false: the head (64 -> 3): wide operand = the input x (64 channels, W + 6 haloed pixels per row, 9 k-groups), narrow
+//               operand = dY (8 channels), pixel r of the wide row meets dY pixel r - kw of output row Rp + 3 - kh.
+// STEM = true:  the stem (3 -> 64): the roles are swapped - wide operand = dY (64 channels, W pixels, 8 k-groups), narrow operand =
+//               the input x (8 channels) with its reflected halo in the ring row (W + 6 padded pixels), pixel j of dY row i meets
+//               padded x pixel j + kw of padded x row i + kh.  Output dW[co][kh][kw][ci] instead of dW[co][kh][kw][ci = wide].
+template <bool STEM> struct WA {
+    static constexpr int ROWS = STEM ? 256 : WH_ROWS;                  // wide-operand pixels (LDS rows of 128 B) per step
+    static constexpr int NKG = ROWS / 32;
+    static constexpr int XT = ROWS * 128;
+    static constexpr int NPX = STEM ? 8 + 320 + 8 : 8 + WH_ROWS + 8;   // narrow ring row: 8 zero pixels | pixel slots | >= 8 zero pixels
+    static constexpr int DYB = NPX * 16;
+    static constexpr int DY0 = WH_NST * XT, ZERO = DY0 + WA_RING * DYB, SMEM = ZERO + DYB;
+    static constexpr int NBIG = ROWS / 32;                             // wide-row DMA pieces per wave (4 waves x 8 rows per piece)
+    static constexpr int NSMALL = STEM ? 2 : 1;                        // narrow-row pieces per wave (the fifth piece of the stem's 262 pixels is issued by every wave)
+};
 }
 
+template <bool STEM>
 __global__ __launch_bounds__(256, 1) void wgrad_head7all_kernel(const bf16_t* __restrict__ P1, const bf16_t* __restrict__ Q1,
                                                                   const bf16_t* __restrict__ P2, const bf16_t* __restrict__ Q2,
                                                                   float* __restrict__ part, const WgHeadDesc d) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [X stage 0..2][dY ring 0..8][zero row]
+    using C = WA<STEM>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [wide stage 0..2][narrow ring 0..8][zero row]
     typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nets = d.group_rows > 0 ? 2 : 1;
     const int bid = blockIdx.x;
     const int chunk = bid % d.chunks, t0 = bid / d.chunks, img_l = t0 % d.imgs_max, net = t0 / d.imgs_max;
     const int n_img = d.n1[net] + d.n2[net];
@@ -215,65 +229,87 @@ __global__ __launch_bounds__(256, 1) void wgrad_head7all_kernel(const bf16_t* __
     const int img = second ? d.img2[net] + img_l - d.n1[net] : d.img1[net] + img_l;
     const bf16_t* P = second ? P2 : P1;
     const bf16_t* Q = second ? Q2 : Q1;
-    (void)nets;
     const bool refl = d.pad_mode == UIG_PAD_REFLECT;
     const int W = d.W, H = d.H;
-    // padded rows this block walks: reflection [-3, H + 3), zero padding [0, H) (rows outside contribute nothing)
-    const int lo = refl ? -3 : 0, tp = refl ? H + 6 : H;
+    // rows of the WIDE operand this block walks: head: padded input rows (reflection [-3, H + 3), zero padding [0, H): rows outside
+    // contribute nothing); stem: the H rows of dY
+    const int lo = (!STEM && refl) ? -3 : 0, tp = (!STEM && refl) ? H + 6 : H;
     const int rp0 = lo + (int)((long)chunk * tp / d.chunks), rp1 = lo + (int)((long)(chunk + 1) * tp / d.chunks);
     const int nk = img_l < n_img ? rp1 - rp0 : 0;
 
-    // zero margins of the ring rows and the zero row (DMAs only ever write pixel slots [8, 8 + 256))
-    for (int i = tid; i < (WA_RING + 1) * (WA_DYB / 16); i += 256) {
-        const int row = i / (WA_DYB / 16), c = i % (WA_DYB / 16);
-        if (row == WA_RING || c < 8 || c >= 8 + 256) *reinterpret_cast<u32x4_t*>(smem + WA_DY0 + row * WA_DYB + c * 16) = u32x4_t{0u, 0u, 0u, 0u};
+    // zero margins of the ring rows and the zero row (the DMAs only ever write the pixel slots from 8 on)
+    for (int i = tid; i < (WA_RING + 1) * C::NPX; i += 256) {
+        const int row = i / C::NPX, c = i % C::NPX;
+        if (row == WA_RING || c < 8 || c >= 8 + (STEM ? 320 : 256)) *reinterpret_cast<u32x4_t*>(smem + C::DY0 + row * C::DYB + c * 16) = u32x4_t{0u, 0u, 0u, 0u};
     }
     __syncthreads();
 
-    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(P), 0, second ? d.p2_bytes : d.p_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Q), 0, second ? d.q2_bytes : d.q_bytes, 0x00020000);
-    unsigned xoff[9];                                  // per piece: byte offset of this lane's source chunk inside the input row
+    // wide = 64-channel tensor (head: Q = x; stem: P = dY), narrow = 8-channel tensor (head: P = dY; stem: Q = x)
+    const __amdgpu_buffer_rsrc_t rsWide = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(STEM ? P : Q), 0,
+                                                                             STEM ? (second ? d.p2_bytes : d.p_bytes) : (second ? d.q2_bytes : d.q_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsNarrow = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(STEM ? Q : P), 0,
+                                                                               STEM ? (second ? d.q2_bytes : d.q_bytes) : (second ? d.p2_bytes : d.p_bytes), 0x00020000);
+    unsigned xoff[C::NBIG];                            // per piece: byte offset of this lane's source chunk inside the wide row
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const int r = 8 * (wave + 4 * i) + (lane >> 3);                // LDS row = padded pixel index; pixel column = r - 3
-        const int c = r - 3;
+    for (int i = 0; i < C::NBIG; ++i) {
+        const int r = 8 * (wave + 4 * i) + (lane >> 3);                // LDS row: head = padded pixel index (column r - 3), stem = pixel column
+        const int c = STEM ? r : r - 3;
         const bool inb = (unsigned)c < (unsigned)W;
-        const bool ok = r < W + 6 && (refl || inb);
-        const int cs = refl ? reflect_idx(c, W) : c;
+        const bool ok = STEM ? inb : (r < W + 6 && (refl || inb));
+        const int cs = (!STEM && refl) ? reflect_idx(c, W) : c;
         const int chk = (lane & 7) ^ (((r >> 1) & 3) << 1);           // 16-byte chunk swizzle (conflict-free transposing reads)
         xoff[i] = ok ? (unsigned)((cs * WH_CI + chk * 8) * 2) : 0xFFFFFFFFu;
     }
-    const unsigned yoff = (wave * 64 + lane) < W ? (unsigned)((wave * 64 + lane) * d.Np * 2) : 0xFFFFFFFFu;   // Np == 8: 16 B per pixel
-    auto issue_dy = [&](int i) {                                       // dY row i of this image -> ring slot i mod 9 (zeros if outside the image)
-        const bool valid = (unsigned)i < (unsigned)H;
-        const int sP = __builtin_amdgcn_readfirstlane((int)((unsigned)(img * H + (valid ? i : 0)) * (unsigned)W * (unsigned)(d.Np * 2)));
-        lds_ptr_t dst = (lds_ptr_t)smem + WA_DY0 + ((i + 9 * 64) % WA_RING) * WA_DYB + (8 + 64 * wave) * 16;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (__attribute__((address_space(3))) void*)dst, 16, (int)(valid ? yoff : 0xFFFFFFFFu), sP, 0, 0);
-    };
-    auto issue = [&](int k) {                                          // step k: input row reflect(rp0 + k) -> stage k % 3, dY row rp0 + k + 3
-        const int rp = rp0 + k;
-        const int hr = refl ? reflect_idx(rp, H) : rp;
-        const int sQ = __builtin_amdgcn_readfirstlane((int)((unsigned)(img * H + hr) * (unsigned)W * (unsigned)(WH_CI * 2)));
-        lds_ptr_t dst = (lds_ptr_t)smem + (k % WH_NST) * WH_XT;
+    unsigned yoff[C::NSMALL];                          // narrow row: 16 B per pixel; head: pixel = slot; stem: slot q = padded column, pixel reflect(q - 3)
 #pragma unroll
-        for (int i = 0; i < 9; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(dst + (wave + 4 * i) * 1024), 16, (int)xoff[i], sQ, 0, 0);
-        issue_dy(rp + 3);
+    for (int i = 0; i < C::NSMALL; ++i) {
+        const int q = 64 * (i == 0 ? wave : 4) + lane;
+        if constexpr (STEM) {
+            const int c = q - 3;
+            const bool inb = (unsigned)c < (unsigned)W;
+            const bool ok = q < W + 6 && (refl || inb);
+            yoff[i] = ok ? (unsigned)((refl ? reflect_idx(c, W) : c) * 16) : 0xFFFFFFFFu;
+        } else {
+            yoff[i] = q < W ? (unsigned)(q * 16) : 0xFFFFFFFFu;
+        }
+    }
+    auto issue_narrow = [&](int i) {                                   // narrow row with index i -> ring slot i mod 9 (zeros if it does not exist)
+        // head: dY row i of the image; stem: PADDED input row i (input row reflect(i), or nothing outside a zero-padded image)
+        const bool valid = (STEM && refl) ? true : (unsigned)i < (unsigned)H;
+        const int row = (STEM && refl) ? reflect_idx(i, H) : (valid ? i : 0);
+        const int sN = __builtin_amdgcn_readfirstlane((int)((unsigned)(img * H + row) * (unsigned)W * 16u));
+        lds_ptr_t base = (lds_ptr_t)smem + C::DY0 + ((i + 9 * 64) % WA_RING) * C::DYB + 8 * 16;
+#pragma unroll
+        for (int k = 0; k < C::NSMALL; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsNarrow, (__attribute__((address_space(3))) void*)(base + 64 * (k == 0 ? wave : 4) * 16), 16,
+                                                     (int)(valid ? yoff[k] : 0xFFFFFFFFu), sN, 0, 0);
     };
+    auto issue = [&](int k) {                                          // step k: wide row rp0 + k -> stage k % 3; narrow row rp0 + k + 3
+        const int rp = rp0 + k;
+        const int hr = (!STEM && refl) ? reflect_idx(rp, H) : rp;
+        const int sW = __builtin_amdgcn_readfirstlane((int)((unsigned)(img * H + hr) * (unsigned)W * (unsigned)(WH_CI * 2)));
+        lds_ptr_t dst = (lds_ptr_t)smem + (k % WH_NST) * C::XT;
+#pragma unroll
+        for (int i = 0; i < C::NBIG; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsWide, (__attribute__((address_space(3))) void*)(dst + (wave + 4 * i) * 1024), 16, (int)xoff[i], sW, 0, 0);
+        issue_narrow(rp + 3);
+    };
+    constexpr int PER_STEP = C::NBIG + C::NSMALL;                       // DMAs per wave and step (10 in both forms)
+    static_assert(PER_STEP == 10, "the counted vmcnt below");
 
-    // ---- fragment addressing: wave w owns input channels 16w..16w+15; four 16-column tiles (tile t = taps kw 2t, 2t+1)
+    // ---- fragment addressing: wave w owns wide channels 16w..16w+15; four 16-column tiles (tile t = taps kw 2t, 2t+1 x 8 narrow channels)
     const int l16 = lane & 15, g = lane >> 4, qq = l16 >> 2, pp = l16 & 3;
     const int k0 = 4 * g + qq;
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
     const unsigned swz = (unsigned)(((k0 >> 1) & 3) << 1);
     const unsigned aoff = (unsigned)(k0 * 128 + (((wave * 2 + (pp >> 1)) ^ swz) << 4) + (pp & 1) * 8);
-    unsigned boff[4];                                                  // inside a ring row: dY pixel r - kw of LDS row r = k0 (+16, +32 kk)
+    unsigned boff[4];                                                  // inside a ring row: head: dY pixel r - kw; stem: padded x pixel j + kw (r, j = k0 + 16 h + 32 kk)
     bool bz[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int kw = 2 * t + (pp >> 1);
         bz[t] = kw >= 7;
-        boff[t] = (unsigned)((8 + k0 - (bz[t] ? 0 : kw)) * 16 + (pp & 1) * 8);
+        boff[t] = (unsigned)((8 + k0 + (bz[t] ? 0 : (STEM ? kw : -kw))) * 16 + (pp & 1) * 8);
     }
     auto tr_read = [&](unsigned addr, auto off) -> bf16x4_t {
         u32x2_t r;
@@ -283,12 +319,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_head7all_kernel(const bf16_t* __
     struct BF { bf16x8_t b[4]; };
     auto read_b = [&](BF& f, unsigned row_base, auto kkc) {            // 8 transposing reads: the four column tiles of one (kh, k-group)
         constexpr int o = decltype(kkc)::value * 32 * 16;
-        const unsigned zb = lds0 + (unsigned)WA_ZERO;
+        const unsigned zb = lds0 + (unsigned)C::ZERO;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const unsigned a = (bz[t] ? zb : row_base) + boff[t];
-            const bf16x4_t lo = tr_read(a, std::integral_constant<int, o>{}), hi = tr_read(a, std::integral_constant<int, o + 16 * 16>{});
-            f.b[t] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const bf16x4_t lo_ = tr_read(a, std::integral_constant<int, o>{}), hi_ = tr_read(a, std::integral_constant<int, o + 16 * 16>{});
+            f.b[t] = bf16x8_t{lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]};
         }
     };
 
@@ -300,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_head7all_kernel(const bf16_t* __
 
     if (nk > 0) {
 #pragma unroll
-        for (int i = -3; i < 3; ++i) issue_dy(rp0 + i);                // the six rows the first step needs besides its own new one
+        for (int i = -3; i < 3; ++i) issue_narrow(rp0 + i);            // the six rows the first step needs besides its own new one
         issue(0);
         if (nk > 1) issue(1);
     }
@@ -310,13 +346,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_head7all_kernel(const bf16_t* __
         __builtin_amdgcn_s_barrier();                      // step ks complete for every wave; everyone is done with step ks-1's stage and ring slot
         if (ks + 2 < nk) issue(ks + 2);
         const int rp = rp0 + ks;
-        unsigned rowb[7];                                   // ring row (or the zero row) of output row i = rp + 3 - kh
+        unsigned rowb[7];                                   // ring row (or the zero row) of tap row kh: head: dY row rp + 3 - kh; stem: padded x row rp - 3 + kh
 #pragma unroll
         for (int kh = 0; kh < 7; ++kh) {
-            const int i = rp + 3 - kh;
-            rowb[kh] = lds0 + (unsigned)(((unsigned)i < (unsigned)H) ? WA_DY0 + (i % WA_RING) * WA_DYB : WA_ZERO);
+            const int i = STEM ? rp - 3 + kh : rp + 3 - kh;
+            const bool valid = (STEM && refl) ? true : (unsigned)i < (unsigned)H;
+            rowb[kh] = lds0 + (unsigned)(valid ? C::DY0 + ((i + 9 * 64) % WA_RING) * C::DYB : C::ZERO);
         }
-        const unsigned sa = lds0 + (unsigned)((ks % WH_NST) * WH_XT) + aoff;
+        const unsigned sa = lds0 + (unsigned)((ks % WH_NST) * C::XT) + aoff;
         auto kgroup = [&](auto kkc) {
             constexpr int o = decltype(kkc)::value * 32 * 128;
             const bf16x4_t alo = tr_read(sa, std::integral_constant<int, o>{}), ahi = tr_read(sa, std::integral_constant<int, o + 16 * 128>{});
@@ -339,17 +376,24 @@ __global__ __launch_bounds__(256, 1) void wgrad_head7all_kernel(const bf16_t* __
         };
         kgroup(std::integral_constant<int, 0>{}); kgroup(std::integral_constant<int, 1>{}); kgroup(std::integral_constant<int, 2>{});
         kgroup(std::integral_constant<int, 3>{}); kgroup(std::integral_constant<int, 4>{}); kgroup(std::integral_constant<int, 5>{});
-        kgroup(std::integral_constant<int, 6>{}); kgroup(std::integral_constant<int, 7>{}); kgroup(std::integral_constant<int, 8>{});
+        kgroup(std::integral_constant<int, 6>{}); kgroup(std::integral_constant<int, 7>{});
+        if constexpr (C::NKG > 8) kgroup(std::integral_constant<int, 8>{});
     }
 
-    // D[ci][col]: lane holds column l16 of tile t (col = 16 t + l16 = kw * 8 + co), rows ci = 16 wave + 4g .. +3
+    // accumulator tile (kh, t): lane holds column l16 (= kw * 8 + narrow channel) of wide channels 16 wave + 4g .. + 3
     float* out = part + ((long)net * d.splits + (long)img_l * d.chunks + chunk) * d.Np * d.ncols;
 #pragma unroll
     for (int kh = 0; kh < 7; ++kh)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int col = 16 * t + l16, kw = col >> 3, co = col & 7;
-            if (kw < 7) *reinterpret_cast<f32x4_t*>(out + (long)co * d.ncols + (kh * 7 + kw) * WH_CI + wave * 16 + 4 * g) = acc[kh][t];
+            const int col = 16 * t + l16, kw = col >> 3, cn = col & 7;
+            if (kw >= 7) continue;
+            if constexpr (STEM) {        // part[n = co (wide)][(kh*7 + kw) * 8 + ci (narrow)]
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[(long)(wave * 16 + 4 * g + e) * d.ncols + (kh * 7 + kw) * 8 + cn] = acc[kh][t][e];
+            } else {                     // part[n = co (narrow)][(kh*7 + kw) * 64 + ci (wide)]
+                *reinterpret_cast<f32x4_t*>(out + (long)cn * d.ncols + (kh * 7 + kw) * WH_CI + wave * 16 + 4 * g) = acc[kh][t];
+            }
         }
 }
 
@@ -376,50 +420,62 @@ int uig_wgrad_head_splits2(int B1, int g1, int B2, int g2, int swap2, int H) {
     return head_all_splits(2, std::max(a, b), H);
 }
 
+// the head (dense operand dY of 8 padded channels, gathered operand x of 64) and, on the all-rows kernel, the stem (dY 64, x 8)
 bool uig_wgrad_head_applicable(int Mh, int Mw, int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int dtype) {
-    return g_wgrad_head && dtype == UIG_BF16 && kH == 7 && kW == 7 && stride == 1 && pad == 3 && Mh == Hq && Mw == Wq &&
-           Mw >= 8 && Mw <= WH_MAXW && Hq >= 4 && Np == 8 && Cq == WH_CI;
+    const bool shape = g_wgrad_head && dtype == UIG_BF16 && kH == 7 && kW == 7 && stride == 1 && pad == 3 && Mh == Hq && Mw == Wq &&
+                       Mw >= 8 && Mw <= WH_MAXW && Hq >= 4;
+    return shape && ((Np == 8 && Cq == WH_CI) || (g_wgrad_head == 1 && Np == WH_CI && Cq == 8));
 }
 
-static int launch_head_all(const void* P, const void* Q, const void* P2, const void* Q2, float* ws, WgHeadDesc d, int splits, hipStream_t s) {
+template <bool STEM>
+static int launch_head_all_t(const void* P, const void* Q, const void* P2, const void* Q2, float* ws, const WgHeadDesc& d, int nets, hipStream_t s) {
+    auto kern = wgrad_head7all_kernel<STEM>;
+    static SmemAttrOnce attr_all;
+    hipError_t e = attr_all.ensure(reinterpret_cast<const void*>(kern), (size_t)WA<STEM>::SMEM);
+    if (e != hipSuccess) return uig_set_error((int)e, "wgrad(head): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3(nets * d.splits), dim3(256), (size_t)WA<STEM>::SMEM, s, (const bf16_t*)P, (const bf16_t*)Q,
+                       (const bf16_t*)(P2 ? P2 : P), (const bf16_t*)(Q2 ? Q2 : Q), ws, d);
+    UIG_LAUNCH_CHECK("uig_wgrad_partial(7x7, all rows)");
+    return 0;
+}
+static int launch_head_all(const void* P, const void* Q, const void* P2, const void* Q2, float* ws, WgHeadDesc d, int splits, hipStream_t s, bool stem = false) {
     const int nets = d.n1[1] + d.n2[1] > 0 ? 2 : 1;
     const int imgs_max = std::max(d.n1[0] + d.n2[0], d.n1[1] + d.n2[1]);
     if (imgs_max <= 0 || splits % imgs_max != 0)
         return uig_set_error(-1, "wgrad(head): splits %d is not images %d x chunks (use uig_wgrad_splits / uig_wgrad_pair_splits / uig_wgrad_pair2_splits)", splits, imgs_max);
     d.imgs_max = imgs_max; d.chunks = splits / imgs_max; d.splits = splits;
-    static SmemAttrOnce attr_all;
-    hipError_t e = attr_all.ensure(reinterpret_cast<const void*>(wgrad_head7all_kernel), (size_t)WA_SMEM);
-    if (e != hipSuccess) return uig_set_error((int)e, "wgrad(head): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(wgrad_head7all_kernel, dim3(nets * splits), dim3(256), (size_t)WA_SMEM, s, (const bf16_t*)P, (const bf16_t*)Q,
-                       (const bf16_t*)(P2 ? P2 : P), (const bf16_t*)(Q2 ? Q2 : Q), ws, d);
-    UIG_LAUNCH_CHECK("uig_wgrad_partial(head, all rows)");
-    return 0;
+    return stem ? launch_head_all_t<true>(P, Q, P2, Q2, ws, d, nets, s) : launch_head_all_t<false>(P, Q, P2, Q2, ws, d, nets, s);
 }
 
 // both generator passes in one launch: network 0 = images [0, g1) of (P, Q) + its share of (P2, Q2), network 1 the rest (see wgrad.hip)
 int uig_launch_wgrad_head_runs(const void* P, const void* Q, const void* P2, const void* Q2, float* ws, int B1, int g1, int B2, int g2, int swap2,
                                int H, int W, int Np, int pad_mode, int splits, hipStream_t s) {
+    const bool stem = Np == WH_CI;                    // 64 dense channels: the stem (narrow operand = the 8-channel input)
+    const int Cq = stem ? 8 : WH_CI;
     WgHeadDesc d{};
-    d.B = B1; d.H = H; d.W = W; d.Np = Np; d.pad_mode = pad_mode; d.ncols = 49 * WH_CI; d.rows_total = B1 * H; d.group_rows = g1 * H;
-    d.p_bytes = (unsigned)((long)B1 * H * W * Np * 2); d.q_bytes = (unsigned)((long)B1 * H * W * WH_CI * 2);
-    d.p2_bytes = (unsigned)((long)B2 * H * W * Np * 2); d.q2_bytes = (unsigned)((long)B2 * H * W * WH_CI * 2);
+    d.B = B1; d.H = H; d.W = W; d.Np = Np; d.pad_mode = pad_mode; d.ncols = 49 * Cq; d.rows_total = B1 * H; d.group_rows = g1 * H;
+    d.p_bytes = (unsigned)((long)B1 * H * W * Np * 2); d.q_bytes = (unsigned)((long)B1 * H * W * Cq * 2);
+    d.p2_bytes = (unsigned)((long)B2 * H * W * Np * 2); d.q2_bytes = (unsigned)((long)B2 * H * W * Cq * 2);
     d.n1[0] = g1; d.img1[0] = 0; d.n1[1] = B1 - g1; d.img1[1] = g1;
     d.n2[0] = swap2 ? B2 - g2 : g2; d.img2[0] = swap2 ? g2 : 0;
     d.n2[1] = swap2 ? g2 : B2 - g2; d.img2[1] = swap2 ? 0 : g2;
-    return launch_head_all(P, Q, P2, Q2, ws, d, splits, s);
+    return launch_head_all(P, Q, P2, Q2, ws, d, splits, s, stem);
 }
 
 int uig_launch_wgrad_head(const void* P, const void* Q, float* ws, int B, int H, int W, int Np, int pad_mode, int splits,
                           int group_images, hipStream_t s) {
+    const bool stem = Np == WH_CI;                    // 64 dense channels: the stem (all-rows kernel only)
+    const int Cq = stem ? 8 : WH_CI;
     WgHeadDesc d{};
-    d.B = B; d.H = H; d.W = W; d.Np = Np; d.pad_mode = pad_mode; d.ncols = 49 * WH_CI; d.rows_total = B * H;
+    d.B = B; d.H = H; d.W = W; d.Np = Np; d.pad_mode = pad_mode; d.ncols = 49 * Cq; d.rows_total = B * H;
     d.splits = splits; d.group_rows = group_images * H;
-    d.p_bytes = (unsigned)((long)B * H * W * Np * 2); d.q_bytes = (unsigned)((long)B * H * W * WH_CI * 2);
+    d.p_bytes = (unsigned)((long)B * H * W * Np * 2); d.q_bytes = (unsigned)((long)B * H * W * Cq * 2);
     if (g_wgrad_head != 2) {      // all seven kernel rows per block
         if (group_images > 0) { d.n1[0] = group_images; d.img1[0] = 0; d.n1[1] = B - group_images; d.img1[1] = group_images; }
         else { d.n1[0] = B; d.img1[0] = 0; }
-        return launch_head_all(P, Q, nullptr, nullptr, ws, d, splits, s);
+        return launch_head_all(P, Q, nullptr, nullptr, ws, d, splits, s, stem);
     }
+    if (stem) return uig_set_error(-1, "wgrad(7x7): the stem shape needs the all-rows kernel");
     const size_t smem = (size_t)WH_NST * WH_STAGE + WH_S;
     static SmemAttrOnce attr_once;
     {
