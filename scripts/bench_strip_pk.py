@@ -17,7 +17,10 @@ def t(fn, n=40):
     e0.record()
     for _ in range(n): fn()
     e1.record(); e1.synchronize(); return e0.elapsed_time(e1) * 1e3 / n
-VARIANTS = {"tile/block": (3, 0, 0), "pk": (1, 0, 0), "pk nolgk": (1, 4, 0), "pk rd0-dma": (1, 8, 0), "pk rdall-dma": (1, 9, 0), "pk setprio": (1, 10, 0)}
+VARIANTS = {"tile/block": (3, 0, 0), "pk": (1, 0, 0), "pk nolgk": (1, 4, 0), "pk rd0-dma": (1, 8, 0), "pk rdall-dma": (1, 9, 0), "pk setprio": (1, 10, 0), "pk xprefetch": (1, 11, 0)}
+if os.environ.get("PK_VARIANTS"):
+    VARIANTS = {k: v for k, v in VARIANTS.items() if k == "tile/block" or k in os.environ["PK_VARIANTS"].split(",")}
+lib.uig_debug_set_mirror(0)      # the input gradient in its border-buffer form on every variant, so that dx is comparable bitwise
 if len(sys.argv) > 1:
     VARIANTS.update({f"pk rot g{g}": (1, 4, int(g)) for g in sys.argv[1:]})
 def select(v):
@@ -45,4 +48,4 @@ for (v, B), xs in sorted(res.items(), key=lambda kv: (kv[0][1], kv[0][0])):
     fs, gs = sorted(a for a, _ in xs), sorted(b for _, b in xs)
     fl = 2.0 * B * 4096 * 256 * 2304 / 1e6
     print(f"  B{B:2d} {v:12s} fwd {fs[len(fs)//2]:6.1f} ({fl/fs[len(fs)//2]:5.0f} TF = {fl/fs[len(fs)//2]/2500:.3f} of peak)   dgrad {gs[len(gs)//2]:6.1f} ({fl/gs[len(gs)//2]:5.0f} TF)")
-lib.uig_debug_set_strip(1); lib.uig_debug_set_strip_pk(0, 0)
+lib.uig_debug_set_strip(1); lib.uig_debug_set_strip_pk(0, 0); lib.uig_debug_set_mirror(1)

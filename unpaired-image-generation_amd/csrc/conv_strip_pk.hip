@@ -276,6 +276,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
         strip_init_acc<MT, NT, WN>(acc, bias, d.Nrows, cur.n_base, wn, lane);
 
         stamp();                                               // 1 / 4: K loop starts
+        [[maybe_unused]] u32x4_t xn[MT];                       // DM == 5: the NEXT step's strip fragments of K half 0, read behind this step's MFMAs
         for (int cc = 0; cc < ncc; ++cc) {
             const int pc = par ^ (cc & 1);                     // region of this chunk's strip; weight stage of step t: pc ^ (t & 1)
             const unsigned char* sx = smem + pc * REG;
@@ -303,7 +304,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                     if (which < 2) { if (w_on) issue_w1(which, w_g2, w_so, w_reg); }
                     else if (p_on) issue_strip_piece(slot, s_base, s_NS, pc ^ 1);
                 };
-                if constexpr (DM == 0 || DM == 4) { dma(0); dma(1); dma(2); }
+                if constexpr (DM == 0 || DM == 4 || DM == 5) { dma(0); dma(1); dma(2); }
                 if constexpr (MIRROR) {
                     // last step of the chunk: the next chunk's strip (issued in steps 0-6) is complete and published by this step's
                     // barrier; its mirror pixels are written HERE, at the top of the step, while the matrix pipe still works off the
@@ -312,7 +313,37 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                     if (last_t && s_on && !(d.mirror & 2)) mirror_fix(pc ^ 1, last_cc ? nxt : cur);
                 }
                 const unsigned char* sw = smem + (pc ^ (t & 1)) * REG + SBUF + (wn * WN + l16) * 128;
-                if constexpr (DM == 3) {                        // all 16 fragment reads of the step first, then the DMAs, then 32 MFMAs
+                if constexpr (DM == 5) {
+                    // the strip chunk is resident for all nine steps: only the WEIGHT fragments need this step's barrier.  The strip
+                    // fragments of half 0 were read at the end of the previous step, behind its MFMAs, so the first MFMA of the step
+                    // waits for four reads instead of eight (and the pipe is not empty while the others arrive)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        u32x4_t xf[MT], wf[NT];
+                        const int co = ((q + 4 * h) ^ wswz) << 4;
+#pragma unroll
+                        for (int a = 0; a < NT; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(sw + a * 16 * 128 + co);
+                        if (h == 0 && !(t == 0 && cc == 0)) {
+#pragma unroll
+                            for (int b = 0; b < MT; ++b) xf[b] = xn[b];
+                        } else {
+#pragma unroll
+                            for (int b = 0; b < MT; ++b) xf[b] = *reinterpret_cast<const u32x4_t*>(sx + ((unsigned)rt[t][b] ^ (unsigned)(h << 6)));
+                        }
+#pragma unroll
+                        for (int a = 0; a < NT; ++a)
+#pragma unroll
+                            for (int b = 0; b < MT; ++b) MmaS<T>::run(wf[a], xf[b], acc[a][b]);
+                    }
+                    if (!last_t) {
+#pragma unroll
+                        for (int b = 0; b < MT; ++b) xn[b] = *reinterpret_cast<const u32x4_t*>(sx + (unsigned)rt[(t + 1) % NTAPS][b]);
+                    } else if (!last_cc) {                     // the next chunk's strip is complete since step 7's barrier
+                        const unsigned char* sxn = smem + (pc ^ 1) * REG;
+#pragma unroll
+                        for (int b = 0; b < MT; ++b) xn[b] = *reinterpret_cast<const u32x4_t*>(sxn + (unsigned)rt[0][b]);
+                    }
+                } else if constexpr (DM == 3) {                 // all 16 fragment reads of the step first, then the DMAs, then 32 MFMAs
                     u32x4_t xf[2][MT], wf[2][NT];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
@@ -451,6 +482,7 @@ int uig_launch_strip_pk(const void* x, const void* wp, const float* bias, void* 
             case 8: return launch_pk<bf16_t, 448, 2, 1, false>(x, wp, bias, y, d, ntiles, s);     // reads of half 0, then the DMAs
             case 9: return launch_pk<bf16_t, 448, 3, 1, false>(x, wp, bias, y, d, ntiles, s);     // all reads up front, then the DMAs
             case 10: return launch_pk<bf16_t, 448, 4, 1, false>(x, wp, bias, y, d, ntiles, s);    // s_setprio around the MFMA clusters
+            case 11: return launch_pk<bf16_t, 448, 5, 1, true>(x, wp, bias, y, d, ntiles, s);     // next step's strip fragments read behind this step's MFMAs
             default: return launch_pk<bf16_t, 448, 0, 1, true>(x, wp, bias, y, d, ntiles, s);
         }
     }
