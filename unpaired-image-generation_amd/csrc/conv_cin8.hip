@@ -202,8 +202,9 @@ int uig_try_conv_cin8(const void* x, const void* wp, const float* bias, const vo
     int nseg = (Wo + C8_BM - 1) / C8_BM;
     d.segw = std::min(C8_BM, ((Wo + nseg - 1) / nseg + 31) / 32 * 32);      // e.g. Wo = 262: 3 segments of 96 instead of 128 + 128 + 6
     nseg = (Wo + d.segw - 1) / d.segw;
-    if ((long)Wo * 10 < (long)nseg * C8_BM * 9) return 0;      // rows that leave > 10 % of the 4-wave segments idle (e.g. the 262-wide padded
-                                                               // gradient of the head: 109 vs 102 us) stay on the generic kernel
+    // (rows that leave > 10 % of the 4-wave segments idle, e.g. the 262-wide padded gradient of the head, used to stay on the generic
+    // kernel: 109 vs 102 us in round 1.  Since the epilogue lost its per-element activation switch this kernel wins there too:
+    // 163 vs 190 us at 16 images, 77 vs 91 at 8, fold excluded.)
     // output rows per block: whole rounds of 512 resident blocks (2 per CU), fewest row-steps per CU; ties go to more rows per
     // block (the 50-KB weight image is loaded once per block)
     {
