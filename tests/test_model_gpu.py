@@ -485,6 +485,50 @@ def test_side_streams_equal_single_stream(graph, monkeypatch):
     m0.close(); m2.close()
 
 
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
+def test_two_rank_data_parallel_step_equals_full_batch(graph, tmp_path):
+    """Two ranks (gloo, both on GPU 0; RCCL refuses two ranks per device) each train on one image of a 2-image batch through the
+    product's data-parallel step - backward in stages, a gradient bucket all-reduced behind each stage (between the stage graphs
+    in graph mode), both generator passes' weight gradients in one launch, 1/world folded into Adam - against ONE process training
+    on the full batch.  InstanceNorm is per sample and every loss is a batch mean, so: sum of the ranks' gradients = 2 x the
+    full-batch gradient, and the parameters agree after two steps; both up to the fp32 summation order.  A bucket reduced before
+    its last gradient had landed would show as a missing contribution here (at world size 1 it cannot)."""
+    import socket
+    import subprocess
+    import sys
+    import unpaired_image_generation_amd as u
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dp_gloo2_worker.py")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    outs = [str(tmp_path / f"r{r}.pt") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(port), outs[r], "1" if graph else "0"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    # the full-batch reference, in this process, while the ranks run
+    torch.manual_seed(31)
+    rA, rB = (torch.rand(2, 3, 64, 64, device="cuda") * 2 - 1 for _ in range(2))
+    torch.manual_seed(9)
+    m = u.CycleGAN(n_blocks=3, dtype=torch.bfloat16, use_graph=graph)
+    m.train_step(rA, rB)
+    gG, gD = m.grp_G.grad.clone().cpu(), m.grp_D.grad.clone().cpu()
+    m.train_step(rA, rB)
+    pG, pD = m.grp_G.flat.cpu(), m.grp_D.flat.cpu()
+    m.close()
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        print(out[-1500:])
+        assert p.returncode == 0 and "DP_GLOO2_OK" in out
+    r0, r1 = (torch.load(o, weights_only=True) for o in outs)
+    for k in ("gG", "gD", "pG", "pD"):
+        assert torch.equal(r0[k], r1[k]), f"ranks disagree on {k}"          # both hold the reduced buffers / identical replicas
+    for k, ref in (("gG", gG), ("gD", gD)):
+        d = (r0[k] * 0.5 - ref).abs().max()
+        assert float(d) <= 2e-4 * float(ref.abs().max()), (k, float(d), float(ref.abs().max()))
+    for k, ref in (("pG", pG), ("pD", pD)):
+        d = (r0[k] - ref).abs()
+        # Adam normalises the step: a gradient element within rounding of zero can flip its 2e-4 step, so bound the mean tightly and the max by one step
+        assert float(d.mean()) <= 2e-6 and float(d.max()) <= 5e-4, (k, float(d.mean()), float(d.max()))
+
+
 def test_graph_step_with_rccl_exchange_world1_and_close():
     """Guards two aborts seen in round 1 (graph capture with a live process group; process exit with graphs + RCCL alive).
     One worker process = one rank, as in production (the process group lives as long as the process):
