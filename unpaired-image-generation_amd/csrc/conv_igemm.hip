@@ -99,18 +99,23 @@ void igemm_kernel(const T* __restrict__ x, const T* __restrict__ wp_, const floa
     const int Cin = d.Cin;
 
     // ---- per-thread row bookkeeping for the gather
+    // (image, row, column) of a thread's staged rows: ONE pair of integer divisions (row 0), the others by carrying - four
+    // runtime divisions per row were ~100 VALU instructions each for every thread of every block, and these layers run 9-18 K-steps
     int hb[RA], wb[RA], ib[RA];
     unsigned vmask = 0;
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-        const int m = m_base + lr + RPP * i;
-        const bool v = m < M;
-        const int mm = v ? m : 0;
-        const int jj0 = mm % d.Mw, t = mm / d.Mw, ii0 = t % d.Mh, b = t / d.Mh;
+    {
+        const int m0 = m_base + lr;
+        int jj0 = m0 % d.Mw, t = m0 / d.Mw, ii0 = t % d.Mh, b = t / d.Mh;
         const bool sw = d.ph_swap[blockIdx.y] != 0;
-        const int ii = sw ? jj0 : ii0, jj = sw ? ii0 : jj0;
-        hb[i] = ii * d.si; wb[i] = jj * d.si; ib[i] = b * d.H * d.W;
-        vmask |= (v ? 1u : 0u) << i;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const bool v = m0 + RPP * i < M;
+            const int ii = sw ? jj0 : ii0, jj = sw ? ii0 : jj0;
+            hb[i] = v ? ii * d.si : 0; wb[i] = v ? jj * d.si : 0; ib[i] = v ? b * d.H * d.W : 0;
+            vmask |= (v ? 1u : 0u) << i;
+            jj0 += RPP;
+            while (jj0 >= d.Mw) { jj0 -= d.Mw; if (++ii0 == d.Mh) { ii0 = 0; ++b; } }
+        }
     }
     int wrow[RB];
     unsigned nmask = 0;
@@ -274,9 +279,25 @@ void igemm_kernel(const T* __restrict__ x, const T* __restrict__ wp_, const floa
                 const int per = d.Mh * d.Mw, im = mw / per, loc = mw - im * per;
                 so = d.in_partial + (((long)im * (d.nphase * (per / 64)) + ph * (per / 64) + loc / 64) * d.Nstore + nw0) * 2;
             }
-            store_tile_via_lds<T, MT, NT>(acc, smem + wave * (64 * 64 * (int)sizeof(T)), lane, b4, d.act, d.slope,
-                                          [&](int r) -> T* { T* pp = out_row(mw + r); return pp ? pp + nw0 : nullptr; },
-                                          so, min(64, M - mw));
+            // the store loop asks for rows mw + r0 + RPI * i in increasing order: coordinates carried from one row to the next
+            // (out_row's four divisions per row and lane were a third of the epilogue)
+            int cj = 0, ci = 0, cb = 0, cm = -1;
+            auto row_walk = [&](int r) -> T* {
+                const int m = mw + r;
+                if (m >= M) return nullptr;
+                if (cm < 0 || m < cm) { cj = m % d.Mw; const int t = m / d.Mw; ci = t % d.Mh; cb = t / d.Mh; }
+                else { cj += m - cm; while (cj >= d.Mw) { cj -= d.Mw; if (++ci == d.Mh) { ci = 0; ++cb; } } }
+                cm = m;
+                T* pp;
+                if (d.compact_out) pp = y + ((long)(cb * d.nphase + ph) * (d.Mh * d.Mw) + ci * d.Mw + cj) * d.ldc;
+                else {
+                    const int ho = ci * d.so + oh0, wo = cj * d.so + ow0;
+                    if (ho >= d.Ho || wo >= d.Wo) return nullptr;
+                    pp = y + ((long)(cb * d.Ho + ho) * d.Wo + wo) * d.ldc;
+                }
+                return pp + nw0;
+            };
+            store_tile_via_lds<T, MT, NT>(acc, smem + wave * (64 * 64 * (int)sizeof(T)), lane, b4, d.act, d.slope, row_walk, so, min(64, M - mw));
             return;
         }
     }
