@@ -47,8 +47,9 @@ void uig_debug_set_tile(int bn);
  * 2 = 128x128 single-buffer strip tiles, 3 = never the persistent (one block per CU, walks its tiles) 256x128 kernel.
  * All uig_debug_set_* hooks write process-global selection state: set them before launching, never concurrently with launches. */
 void uig_debug_set_strip(int on);
-/* tuning hook of the persistent strip kernel: dm = DMA issue placement (0 top of the K-step, 1 spread between MFMA groups),
- * grid = persistent grid size (0 = one block per CU) */
+/* tuning hook of the persistent strip kernel: dm = K-loop variant (0 default: DMA issue at the top of the K-step, the next step's
+ * strip fragments read behind this step's MFMAs; 12 = without that prefetch; 2 / 4 / 8 / 9 / 10 = the rejected variants of DESIGN
+ * §3.2), grid = persistent grid size (0 = one block per CU) */
 void uig_debug_set_strip_pk(int dm, int grid);
 /* tuning / test hook: 1 (default) = uig_reflect3x3_dgrad_mirror_applicable may say 1; 0 = it never does (A/B against the border GEMM);
  * 3 / 5 / 7 = diagnostic timing builds of the mirror kernel WITHOUT its per-chunk / first-chunk / any mirror sums (wrong results:

@@ -17,7 +17,7 @@ def t(fn, n=40):
     e0.record()
     for _ in range(n): fn()
     e1.record(); e1.synchronize(); return e0.elapsed_time(e1) * 1e3 / n
-VARIANTS = {"tile/block": (3, 0, 0), "pk": (1, 0, 0), "pk nolgk": (1, 4, 0), "pk rd0-dma": (1, 8, 0), "pk rdall-dma": (1, 9, 0), "pk setprio": (1, 10, 0), "pk xprefetch": (1, 11, 0)}
+VARIANTS = {"tile/block": (3, 0, 0), "pk": (1, 0, 0), "pk no-xprefetch": (1, 12, 0), "pk nolgk": (1, 4, 0), "pk rd0-dma": (1, 8, 0), "pk rdall-dma": (1, 9, 0), "pk setprio": (1, 10, 0)}
 if os.environ.get("PK_VARIANTS"):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k == "tile/block" or k in os.environ["PK_VARIANTS"].split(",")}
 lib.uig_debug_set_mirror(0)      # the input gradient in its border-buffer form on every variant, so that dx is comparable bitwise

@@ -323,7 +323,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                         const int co = ((q + 4 * h) ^ wswz) << 4;
 #pragma unroll
                         for (int a = 0; a < NT; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(sw + a * 16 * 128 + co);
-                        if (h == 0 && !(t == 0 && cc == 0)) {
+                        if (h == 0 && !(t == 0 && (MIRROR || cc == 0))) {
 #pragma unroll
                             for (int b = 0; b < MT; ++b) xf[b] = xn[b];
                         } else {
@@ -338,7 +338,8 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                     if (!last_t) {
 #pragma unroll
                         for (int b = 0; b < MT; ++b) xn[b] = *reinterpret_cast<const u32x4_t*>(sx + (unsigned)rt[(t + 1) % NTAPS][b]);
-                    } else if (!last_cc) {                     // the next chunk's strip is complete since step 7's barrier
+                    } else if (!MIRROR && !last_cc) {          // the next chunk's strip is complete since step 7's barrier (mirror kernel: its
+                                                               // mirror pixels are only published by the NEXT barrier - fresh reads there)
                         const unsigned char* sxn = smem + (pc ^ 1) * REG;
 #pragma unroll
                         for (int b = 0; b < MT; ++b) xn[b] = *reinterpret_cast<const u32x4_t*>(sxn + (unsigned)rt[0][b]);
@@ -474,7 +475,8 @@ int uig_launch_strip_pk(const void* x, const void* wp, const float* bias, void* 
     const int ntiles = d.B * tpi * (d.Nrows / 128);
     if (dtype == UIG_BF16) {
         if (d.mirror) return d.dbg != nullptr ? launch_pk<bf16_t, 448, 0, 1, true, true, true>(x, wp, bias, y, d, ntiles, s)
-                                              : launch_pk<bf16_t, 448, 0, 1, true, false, true>(x, wp, bias, y, d, ntiles, s);
+                                              : (g_pk_dm == 12 ? launch_pk<bf16_t, 448, 0, 1, true, false, true>(x, wp, bias, y, d, ntiles, s)
+                                                               : launch_pk<bf16_t, 448, 5, 1, true, false, true>(x, wp, bias, y, d, ntiles, s));
         if (d.dbg != nullptr) return launch_pk<bf16_t, 448, 0, 1, true, true>(x, wp, bias, y, d, ntiles, s);
         switch (g_pk_dm) {      // tuning variants (A/B in one process: scripts/bench_strip_pk.py)
             case 2: return launch_pk<bf16_t, 448, 0, 0, true>(x, wp, bias, y, d, ntiles, s);      // XOR swizzle (for the bank-conflict counters)
@@ -482,8 +484,8 @@ int uig_launch_strip_pk(const void* x, const void* wp, const float* bias, void* 
             case 8: return launch_pk<bf16_t, 448, 2, 1, false>(x, wp, bias, y, d, ntiles, s);     // reads of half 0, then the DMAs
             case 9: return launch_pk<bf16_t, 448, 3, 1, false>(x, wp, bias, y, d, ntiles, s);     // all reads up front, then the DMAs
             case 10: return launch_pk<bf16_t, 448, 4, 1, false>(x, wp, bias, y, d, ntiles, s);    // s_setprio around the MFMA clusters
-            case 11: return launch_pk<bf16_t, 448, 5, 1, true>(x, wp, bias, y, d, ntiles, s);     // next step's strip fragments read behind this step's MFMAs
-            default: return launch_pk<bf16_t, 448, 0, 1, true>(x, wp, bias, y, d, ntiles, s);
+            case 12: return launch_pk<bf16_t, 448, 0, 1, true>(x, wp, bias, y, d, ntiles, s);     // the form before the cross-barrier prefetch (A/B; also switches the mirror kernel back)
+            default: return launch_pk<bf16_t, 448, 5, 1, true>(x, wp, bias, y, d, ntiles, s);     // next step's strip fragments read behind this step's MFMAs
         }
     }
     if (d.mirror) return uig_set_error(-1, "conv_strip_pk: mirror pixels are a bf16 path");
