@@ -149,18 +149,23 @@ class CycleGANOracle:
             for p in n.parameters():
                 p.requires_grad_(flag)
 
+    def _run(self, net, x):
+        """evaluate one of the four networks (hook: oracle/lowprec_oracle.py re-states the product's low-precision storage points here)"""
+        return net(x)
+
     def train_step(self, real_A: torch.Tensor, real_B: torch.Tensor) -> dict:
         mse = lambda p, t: F.mse_loss(p, torch.full_like(p, t))
-        fake_B = self.G_A(real_A); rec_A = self.G_B(fake_B)
-        fake_A = self.G_B(real_B); rec_B = self.G_A(fake_A)
+        run = self._run
+        fake_B = run(self.G_A, real_A); rec_A = run(self.G_B, fake_B)
+        fake_A = run(self.G_B, real_B); rec_B = run(self.G_A, fake_A)
         # --- generators (D frozen)
         self._req((self.D_A, self.D_B), False)
         self.opt_G.zero_grad()
-        idt_A = self.G_A(real_B); idt_B = self.G_B(real_A)
+        idt_A = run(self.G_A, real_B); idt_B = run(self.G_B, real_A)
         l_idt_A = F.l1_loss(idt_A, real_B) * self.lam * self.lam_idt
         l_idt_B = F.l1_loss(idt_B, real_A) * self.lam * self.lam_idt
-        l_G_A = mse(self.D_A(fake_B), 1.0)
-        l_G_B = mse(self.D_B(fake_A), 1.0)
+        l_G_A = mse(run(self.D_A, fake_B), 1.0)
+        l_G_B = mse(run(self.D_B, fake_A), 1.0)
         l_cyc_A = F.l1_loss(rec_A, real_A) * self.lam
         l_cyc_B = F.l1_loss(rec_B, real_B) * self.lam
         (l_G_A + l_G_B + l_cyc_A + l_cyc_B + l_idt_A + l_idt_B).backward()
@@ -169,8 +174,8 @@ class CycleGANOracle:
         self._req((self.D_A, self.D_B), True)
         self.opt_D.zero_grad()
         pf_B, pf_A = self.pool_B.query(fake_B.detach()), self.pool_A.query(fake_A.detach())
-        l_D_A = 0.5 * (mse(self.D_A(real_B), 1.0) + mse(self.D_A(pf_B), 0.0)); l_D_A.backward()
-        l_D_B = 0.5 * (mse(self.D_B(real_A), 1.0) + mse(self.D_B(pf_A), 0.0)); l_D_B.backward()
+        l_D_A = 0.5 * (mse(run(self.D_A, real_B), 1.0) + mse(run(self.D_A, pf_B), 0.0)); l_D_A.backward()
+        l_D_B = 0.5 * (mse(run(self.D_B, real_A), 1.0) + mse(run(self.D_B, pf_A), 0.0)); l_D_B.backward()
         self.opt_D.step()
         self.last = dict(fake_B=fake_B.detach(), fake_A=fake_A.detach(), rec_A=rec_A.detach(), rec_B=rec_B.detach())
         return {"idt_A": l_idt_A.item(), "idt_B": l_idt_B.item(), "G_A": l_G_A.item(), "G_B": l_G_B.item(),

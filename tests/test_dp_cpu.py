@@ -169,3 +169,19 @@ def test_flat_group_views_and_world1_noop():
     x = GradExchange()
     assert x.world == 1 and x.start(grp.grad) is None
     x.wait(None)
+
+
+def test_param_views_follow_the_interleaved_layout():
+    """FlatGroup.param_views (per-parameter Adam state in checkpoints): view i of the grad buffer IS params[i].grad, for the
+    interleaved two-network layout as for a single network"""
+    from unpaired_image_generation_amd.dp import FlatGroup
+    (GA, _), (GB, _) = _build(1), _build(2)
+    grp = FlatGroup((GA, GB), "cpu")
+    assert grp.interleaved and grp.params[0] is next(GA.parameters()) and grp.params[1] is next(GB.parameters())
+    views = grp.param_views(grp.grad)
+    assert len(views) == len(grp.params)
+    for v, p in zip(views, grp.params):
+        assert v.shape == p.shape and v.data_ptr() == p.grad.data_ptr()
+    grp.m.copy_(torch.arange(grp.m.numel(), dtype=torch.float32))
+    mv = grp.param_views(grp.m)
+    assert float(mv[1].reshape(-1)[0]) == grp._starts[1]

@@ -313,6 +313,11 @@ def test_train_step_config2_b4_256_bf16_graph_vs_oracle():
     m = u.CycleGAN(n_blocks=9, dtype=torch.bfloat16, use_graph=True)
     _load_oracle_weights(m, o)
     rA, rB = torch.rand(4, 3, 256, 256) * 2 - 1, torch.rand(4, 3, 256, 256) * 2 - 1
+    # tensor-level evidence at the bench shapes (round 3): step 0 also against the same-rounding emulation of the bf16 step
+    # (oracle/lowprec_oracle.py: bf16 storage points, bf16 conv operands, fp32 accumulate) on the same weights and inputs
+    from oracle.lowprec_oracle import LowPrecOracle
+    torch.manual_seed(3)
+    e = LowPrecOracle(n_blocks=9)
     for step, tol in ((0, 3e-2), (1, 1e-1)):
         lo = o.train_step(rA, rB)
         lm = m.train_step(rA.cuda(), rB.cuda())
@@ -320,6 +325,22 @@ def test_train_step_config2_b4_256_bf16_graph_vs_oracle():
         print(f"step {step}:", {k: (round(lo[k], 4), round(lm[k], 4)) for k in lo})
         for k in lo:
             assert abs(lo[k] - lm[k]) <= tol * max(1.0, abs(lo[k])), (step, k, lo[k], lm[k])
+        if step == 0:
+            le = e.train_step(rA, rB)
+            print("step 0 vs bf16 emulation:", {k: (round(le[k], 4), round(lm[k], 4)) for k in le})
+            for k in le:      # stated: 1 % (same roundings; what is left is fp32 summation order across rounding boundaries)
+                assert abs(le[k] - lm[k]) <= 1e-2 * max(1.0, abs(le[k])), (k, le[k], lm[k])
+            fb = u.ops.from_nhwc(m.last_fake_B, 3).cpu()
+            d = (fb - e.last["fake_B"]).abs()
+            print("fake_B vs bf16 emulation: L-inf", float(d.max()), "mean", float(d.mean()), "| vs fp32 oracle L-inf", float((fb - o.last["fake_B"]).abs().max()))
+            assert float(d.max()) <= 0.12 and float(d.mean()) <= 5e-3
+            assert float((fb - o.last["fake_B"]).abs().max()) <= 0.12      # bf16 drifts 4-7e-2 from fp32 on the tanh output
+            for name, mine, theirs in (("G_A ResBlock 5 conv 2", m.G_A[14].b[5].weight.grad, e.G_A[14].b[5].weight.grad),
+                                       ("G_B up1", m.G_B[19].weight.grad, e.G_B[19].weight.grad),
+                                       ("D_A 256->512", m.D_A[8].weight.grad, e.D_A[8].weight.grad)):
+                rel = float((mine.cpu() - theirs).norm() / theirs.norm())
+                print(f"weight gradient {name}: relative L2 vs bf16 emulation {rel:.3e}")
+                assert rel <= 0.10, (name, rel)
     m.close()
 
 
@@ -545,3 +566,18 @@ def test_graph_step_with_rccl_exchange_world1_and_close():
     print(r.stdout[-2000:]); print(r.stderr[-3000:])
     assert r.returncode == 0, f"worker exit status {r.returncode}"
     assert "RCCL_WORLD1_OK" in r.stdout
+
+
+def test_process_group_lifecycle_then_new_graph_model():
+    """Round 2 saw `Fatal Python error: Segmentation fault` inside CUDAGraph.replay: the first graph replay of a freshly captured
+    model after an in-process init_process_group('nccl') ... CycleGAN.close() ... destroy_process_group().  The whole sequence -
+    group up, graph steps with the forced RCCL exchange, close(), group down, NEW graph model trained, twice over - in ONE
+    process (tests/_pg_lifecycle_worker.py, faulthandler on; a worker so that a native fault fails this test with its traceback
+    instead of taking the pytest session down)."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_pg_lifecycle_worker.py")
+    r = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-2000:]); print(r.stderr[-6000:])
+    assert r.returncode == 0, f"worker exit status {r.returncode}"
+    assert "PG_LIFECYCLE_OK" in r.stdout

@@ -177,17 +177,25 @@ class CycleGAN:
         res.update(fake_B=fake_B.detach(), fake_A=fake_A.detach(), losses=losses)
         self.last_fake_B = res["fake_B"]
         ctx = (lambda k: ops.deferred_param_grads(self.device)) if self.defer_join else None
-        # both generator passes back-propagate through the same layer pairs: one weight-gradient launch per pair for both batches
+        # both generator passes back-propagate through the same layer pairs: one weight-gradient launch per pair for both batches.
+        # The LAST stage index is yielded only after the region has closed (its exit flushes a layer pair that was visited once
+        # into grp_G.grad) and the discriminators are un-frozen: whoever drives this generator starts the last bucket's all-reduce
+        # at that yield, so nothing may write a gradient behind it - in eager mode as in a captured stage graph.
+        last = None
         with ops.combined_pass_wgrad(self.device) if (self.batch_fused and self.paired) else contextlib.nullcontext():
             if taps:
                 # pass 1 (the 4B-image pass) is the LAST part of the backward pass and a chain through its ResBlocks: cut there
                 cuts = [taps[i] for i in self.cuts_G]
-                yield from staged_backward(losses, cuts, self._stage_params((self.G_A, self.G_B), self.cuts_G), ctx)
+                for k in staged_backward(losses, cuts, self._stage_params((self.G_A, self.G_B), self.cuts_G), ctx):
+                    if last is not None:
+                        yield last
+                    last = k
             else:
                 with ctx(0) if ctx else contextlib.nullcontext():
                     ops.backward_unit(losses)
-                yield 0
+                last = 0
         self.grp_D.set_requires_grad(True)
+        yield last
 
     def _d_phase(self, xa, xb, fake_B, fake_A):
         res = {}
@@ -256,14 +264,34 @@ class CycleGAN:
             st = getattr(grp, "state16", None)
             if st is not None and self.graph_active:        # graph mode keeps the authoritative counter on the device
                 step = int(st[0].item())
-            sd["opt_" + name] = {"m": grp.m.clone(), "v": grp.v.clone(), "step": step}
+            # Adam moments PER PARAMETER, keyed by network and state_dict name: independent of how FlatGroup lays the flat buffers
+            # out (the interleaved layout of round 2 permuted parameters at unchanged numel - a raw flat copy would load silently wrong)
+            keys = self._param_keys(name)
+            sd["opt_" + name] = {"format": "per_param_v1", "step": step,
+                                 "m": {k: t.clone() for k, t in zip(keys, grp.param_views(grp.m))},
+                                 "v": {k: t.clone() for k, t in zip(keys, grp.param_views(grp.v))}}
         return sd
+
+    def _param_keys(self, which):
+        """'<net>.<state_dict name>' of every parameter of an optimiser group, in the order of its FlatGroup.params"""
+        nets = (("G_A", self.G_A), ("G_B", self.G_B)) if which == "G" else (("D_A", self.D_A), ("D_B", self.D_B))
+        grp = self.grp_G if which == "G" else self.grp_D
+        by_id = {id(p): f"{nn}.{k}" for nn, net in nets for k, p in net.named_parameters()}
+        return [by_id[id(p)] for p in grp.params]
 
     def load_state_dict(self, sd):
         self.load_state_dicts(*sd["nets"])
         for name, grp in (("G", self.grp_G), ("D", self.grp_D)):
             o = sd["opt_" + name]
-            grp.m.copy_(o["m"]); grp.v.copy_(o["v"]); grp.step = int(o["step"])
+            if o.get("format") != "per_param_v1":
+                raise ValueError("checkpoint holds Adam state as raw flat buffers (written before the per-parameter format): their "
+                                 "parameter order is not recorded and differs between layouts of the same size - refusing to load it")
+            keys = self._param_keys(name)
+            if set(keys) != set(o["m"]) or set(keys) != set(o["v"]):
+                raise KeyError(f"optimizer state keys differ: {sorted(set(keys) ^ set(o['m']))[:6]}")
+            for k, mv, vv in zip(keys, grp.param_views(grp.m), grp.param_views(grp.v)):
+                mv.copy_(o["m"][k]); vv.copy_(o["v"][k])
+            grp.step = int(o["step"])
             st = getattr(grp, "state16", None)
             if st is not None:
                 st[0] = grp.step
@@ -328,8 +356,12 @@ class CycleGAN:
                     delattr(st, name)                       # g1 / g2 are lists of stage graphs
             st.__dict__.clear()
         del st
-        self.__dict__.pop("_packers", None)
-        self.__dict__.pop("_upd_stream", None)
+        # tensors that live in the graphs' private memory pool (last outputs) and the device-side Adam records go with the graphs:
+        # nothing of this model may keep a block of that pool, or a pointer a later capture could bake in, alive
+        for name in ("_packers", "_upd_stream", "last_fake_B", "last_losses"):
+            self.__dict__.pop(name, None)
+        for grp in (self.grp_G, self.grp_D):
+            grp.__dict__.pop("state16", None)           # graph_train_step keeps grp.step in step with the device counter
         self.xchg.close()
         ops.release_side_streams(self.device)
         gc.collect()

@@ -52,6 +52,10 @@ class FlatGroup:
     def zero_grad(self):
         self.grad.zero_()
 
+    def param_views(self, flat: torch.Tensor):
+        """views of a flat buffer of this group's layout (grad / m / v), one per parameter, in self.params order and shape"""
+        return [flat[a:a + p.numel()].view(p.shape) for a, p in zip(self._starts, self.params)]
+
     def bucket_range(self, p0: int, p1: int):
         """(start, end) of the flat slice holding parameters p0 <= index < p1 (index within ONE network's parameters()
         order) of every network of the group.  Needs the interleaved layout (or a single network)."""

@@ -46,8 +46,18 @@ def _side_stream(device) -> torch.cuda.Stream:
 
 
 def release_side_streams(device) -> None:
-    """forget the parameter-gradient side stream of `device` (CycleGAN.close(): ordered teardown)"""
-    _SIDE_STREAMS.pop(torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), None)
+    """forget everything this module holds for `device` between calls (CycleGAN.close(): ordered teardown): the
+    parameter-gradient side stream, the deferred-join flag and any weight-gradient stash an interrupted backward left behind
+    (it would pin activations of a dead model and be picked up by the next model's first layer pair)"""
+    idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    _SIDE_STREAMS.pop(idx, None)
+    _DEFER_JOIN.pop(idx, None)
+    _WG_STASH.pop(idx, None)
+
+
+def device_state_empty() -> bool:
+    """True when no stream, flag or stashed tensor of any model is held at module level (after every model was closed)"""
+    return not _SIDE_STREAMS and not _WG_STASH and not any(_DEFER_JOIN.values())
 
 
 class combined_pass_wgrad:
@@ -429,12 +439,12 @@ def _dy_padded(spec: ConvSpec, dy: torch.Tensor) -> torch.Tensor:
 
 
 def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, pair=None, res_add=None, mx=None, bst=None) -> torch.Tensor:
-    """bst = (x_in, stats, act, slope) of the InstanceNorm whose backward will consume the returned dx as its dy: where the launch
-    supports it (bf16 strip / fp8 kernel with the border terms), its backward statistics come out of this launch's epilogue and
-    travel on dx as `_uig_bst_partial`."""
     """aten::convolution_backward, input gradient.  dy: (B,Ho,Wo,cout_p).  pair = (wp_dgrad2, None, group_images).
     res_add: a second gradient of the input (the ResBlock skip path's) to be summed in: fused into the launch's epilogue
-    where the kernel supports it, one in-place add otherwise."""
+    where the kernel supports it, one in-place add otherwise.
+    bst = (x_in, stats, act, slope) of the InstanceNorm whose backward will consume the returned dx as its dy: where the launch
+    supports it (bf16 strip / fp8 kernel with the border terms), its backward statistics come out of this launch's epilogue and
+    travel on dx as `_uig_bst_partial`."""
     B, Ho, Wo, Cd = dy.shape
     H, W = in_hw
     s = _stream()
