@@ -131,6 +131,24 @@ int uig_reflect3x3_dgrad_mirror_applicable(int B, int H, int W, int C, int Nrows
 int uig_reflect3x3_dgrad_mirror(const void* dy, const void* wp, const void* wp2, int group_images, const void* res_add, void* dx,
                                 int B, int H, int W, int C, int Nrows, int ldc, int dtype, void* stream);
 
+/* ---- 3x3 stride-1 pad-1 convolution (zero or reflection padding) that applies the InstanceNorm(+ReLU / LeakyReLU) IN FRONT of
+ * it to its own input as it is staged (round 3; replaces aten::instance_norm's apply pass + aten::convolution of a ResBlock's
+ * second convolution by ONE launch):
+ *   y = conv(act((x_raw - mean) * rstd), wp) + bias,   (mean, rstd) = nrm_stats fp32[B][Cin][2] (uig_instnorm_finalize)
+ * x_raw (B,H,W,Cin): the raw output of the previous convolution; nrm_act / nrm_slope: the norm's activation.
+ * h_out (optional, shape of x_raw): receives the normalised activations (bitwise what uig_instnorm_act_fwd_pre would write) - the
+ * backward pass's weight-gradient operand.
+ * wp / bias / wp2 / bias2 / group_images / in_partial / y / ldc / act / slope: as uig_conv_gather_ex (direct gather, Nstore = Nrows).
+ * bf16, persistent strip kernel shapes only: uig_conv3x3_innorm_applicable. */
+int uig_conv3x3_innorm_applicable(int B, int H, int W, int Cin, int Nrows, int pad_mode, int ldc, int dtype);
+int uig_conv3x3_innorm_fwd(const void* x_raw, const float* nrm_stats, int nrm_act, float nrm_slope, void* h_out,
+                           const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images, float* in_partial, void* y,
+                           int B, int H, int W, int Cin, int Nrows, int pad_mode, int ldc, int act, float slope, int dtype, void* stream);
+void uig_debug_set_normconv(int on);
+/* the finalize launch of uig_instnorm_act_fwd_pre on its own: partial (in_partial of uig_conv_gather_ex, nslab per image) ->
+ * stats (mean, rstd) fp32[B][C][2] */
+int uig_instnorm_finalize(const float* partial, int nslab, float* stats, int B, int64_t HW, int C, float eps, void* stream);
+
 /* ---- MX block-scaled fp8 path (BASELINE.json configs[4]): the 3x3 stride-1 pad-1 convolutions (forward: gather_mode direct,
  * zero or reflection padding; input gradient: gather_mode transposed, zero padding + border_add) on
  * v_mfma_scale_f32_16x16x128_f8f6f4.  Operands: OCP e4m3 bytes with one E8M0 scale byte per 32 consecutive channels

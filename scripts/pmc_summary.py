@@ -4,7 +4,7 @@ KiB, and on gfx950 FETCH_SIZE counts 128-B read requests as 64 B for wide coales
 import csv, glob, json, sys, collections
 src, out = sys.argv[1], sys.argv[2]
 res = {"kernel": None, "launches": 0}
-for name in ("fetch", "write", "sq"):
+for name in ("fetch", "write", "sq", "sq2"):
     f = glob.glob(f"{src}/{name}/*/*_counter_collection.csv")
     if not f:
         continue

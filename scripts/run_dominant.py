@@ -7,12 +7,13 @@ import unpaired_image_generation_amd as u
 from unpaired_image_generation_amd import ops, networks
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+stats = len(sys.argv) > 2 and sys.argv[2] == "stats"      # also emit the following InstanceNorm's statistics, as every forward launch of the step does
 dt = torch.bfloat16
 layer = networks.ConvLayer("conv", 256, 256, 3, 1, 1, "reflect", dtype=dt, device="cuda")
 layer2 = networks.ConvLayer("conv", 256, 256, 3, 1, 1, "reflect", dtype=dt, device="cuda")
 layer.repack(); layer2.repack()
 x = (torch.rand(16, 64, 64, 256, device="cuda") * 2 - 1).to(dt)     # the paired 4B-image launch of the batch-4 step
 for _ in range(n):
-    y = ops.conv_forward(layer.spec, x, layer.wp_fwd, layer.bias, pair=(layer2.wp_fwd, layer2.bias, 8))
+    y = ops.conv_forward(layer.spec, x, layer.wp_fwd, layer.bias, pair=(layer2.wp_fwd, layer2.bias, 8), want_in_stats=stats)
 torch.cuda.synchronize()
 print("done", float(y.float().abs().mean()))

@@ -907,3 +907,66 @@ def test_instnorm_backward_statistics_from_dgrad_epilogue(B, group, act):
     ref = xr.grad
     got = ops.from_nhwc(dx1, 256).cpu()
     assert (got - ref).abs().max() <= 2.5e-2 * float(ref.abs().max()), float((got - ref).abs().max()) / float(ref.abs().max())
+
+
+@pytest.mark.parametrize("B,paired", [(16, True), (8, False), (12, True), (24, True)], ids=["paired16", "single8", "paired12", "paired24-3tiles"])
+def test_norm_conv_resblock_equals_apply_pass_path(B, paired, monkeypatch):
+    """Round 3: the second convolution of a ResBlock applies the InstanceNorm + ReLU in front of it to its own input strip in LDS
+    (ops.NormConvFn, conv_strip_pk_kernel<NORM>): no apply pass between the block's two convolutions (its finalize launch stays).  Whole ResBlocks (one
+    network, and two networks in paired launches; 1, 2 and 3 tiles per persistent block) forward + backward against the path
+    with the apply pass: the normalised activations are bitwise what the apply kernel writes, so the block output, the input
+    gradient and every parameter gradient are bitwise equal; and the block output against the oracle (stock torch ResBlock on
+    bf16-rounded weights), 1.6e-2 * max|ref|.  Also without autograd (inference: nothing stored for a backward pass)."""
+    u, ops, networks = _mods()
+    from oracle.torch_oracle import ResBlock as OResBlock
+    dt = torch.bfloat16
+    torch.manual_seed(500 + B)
+    nets = [torch.nn.Sequential(networks.ResBlock(256, dt, "cuda")) for _ in range(2 if paired else 1)]
+    for n in nets:
+        rb = n[0]
+        with torch.no_grad():
+            rb.b[1].bias.normal_(0, 0.1); rb.b[5].bias.normal_(0, 0.1)
+            rb.b[1].weight.mul_(1.5)
+        rb.b[1].emit_in_stats = rb.b[5].emit_in_stats = True
+    x = (torch.rand(B, 64, 64, 256, device="cuda") * 2 - 1).to(dt)
+    dy = (torch.randn(B, 64, 64, 256, device="cuda") * 0.5).to(dt)
+    calls = []
+    real = ops.norm_conv
+    monkeypatch.setattr(ops, "norm_conv", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+
+    def run(flag, grad=True):
+        monkeypatch.setattr(ops, "NORM_CONV", flag)
+        for n in nets:
+            for p in n.parameters():
+                p.grad = None
+        xp = x.clone().requires_grad_(grad)
+        with (torch.enable_grad() if grad else torch.no_grad()):
+            y = networks.pair_forward_phys(nets[0], nets[1], xp) if paired else nets[0][0](xp)
+        if not grad:
+            return (y,)
+        y.backward(dy)
+        return (y.detach(), xp.grad.clone(), *[p.grad.clone() for n in nets for p in n.parameters()])
+
+    n0 = len(calls)
+    fused = run(True)
+    assert len(calls) == n0 + 1, "the fused launch did not run"
+    assert u.lib.lib().uig_debug_last_conv_kernel() in (u.lib.K_STRIP_PK, u.lib.K_IGEMM)
+    plain = run(False)
+    assert len(calls) == n0 + 1
+    for i, (a, b) in enumerate(zip(fused, plain)):
+        assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
+    fused_ng = run(True, grad=False)
+    assert len(calls) == n0 + 2 and torch.equal(fused_ng[0], fused[0])
+    # oracle
+    g = B // 2 if paired else B
+    outs = []
+    for i, n in enumerate(nets):
+        o = OResBlock(256)
+        sd = {k: (_bf(v) if k.endswith("weight") else v.clone()) for k, v in n[0].state_dict().items()}
+        o.load_state_dict({k: v.cpu() for k, v in sd.items()})
+        xs = ops.from_nhwc(x[:g] if i == 0 else x[g:], 256).cpu() if paired else ops.from_nhwc(x, 256).cpu()
+        with torch.no_grad():
+            outs.append(o(xs))
+    ref = torch.cat(outs)
+    got = ops.from_nhwc(fused[0], 256).cpu()
+    assert float((got - ref).abs().max()) <= 1.6e-2 * float(ref.abs().max())

@@ -30,6 +30,14 @@ struct StripDesc {
     // persistent bf16 kernel only: 1 = this launch is the input gradient of a REFLECTION-padded 3x3 convolution on a 64-wide map and
     // the kernel folds the mirrored-border terms itself (conv_strip_pk.hip, "mirror pixels"): no border_add buffer, no border GEMM
     int mirror;
+    // persistent bf16 kernel only (round 3): the input x is the RAW output of the convolution in front of an InstanceNorm(+ReLU /
+    // LeakyReLU) and this launch applies that norm itself, on the strip as it sits in LDS (conv_strip_pk.hip, "norm strip"): no
+    // apply pass between the two convolutions of a ResBlock.  nrm_stats = the norm's (mean, rstd) fp32[B][Cin][2] (the finalize
+    // launch's output), nrm_act / nrm_slope its activation; nrm_h (optional): tensor of x's shape that receives the normalised
+    // activations - what the apply pass would have written: the backward pass's weight-gradient operand.
+    const float* nrm_stats;
+    int nrm_act; float nrm_slope;
+    void* nrm_h;
 };
 
 struct UigBst { const void* x; const float* stats; float* partial; int act; float slope; };

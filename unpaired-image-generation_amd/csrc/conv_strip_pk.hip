@@ -40,7 +40,21 @@
 // (every strip piece of the chunk has landed and been published by then: pieces are issued in steps 0-6), visible to all after
 // the next step's barrier.  12 (+66) pixels x 8 chunks of work per K chunk against 36 x 512 MFMAs: nothing, and the 22-us
 // eight-phase border GEMM in front of every input-gradient launch (uig_reflect3x3_dgrad_border) and the epilogue's border loads go.
-template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false, bool MIRROR = false>
+//
+// NORM (bf16; round 3): the input x is the raw output of the convolution in front of an InstanceNorm(+ReLU) and THIS launch applies
+// the norm - conv2 of a ResBlock consumes conv1's output directly, the apply pass between them (one read + one write of the whole
+// tensor per ResBlock and pass: 18 launches of a train step) is gone.  The strip arrives in LDS by DMA as before and is rewritten IN
+// PLACE piece by piece: in tap-step t a wave normalises the 1-KiB piece it DMA'd itself in step t - 1 (landed by its own vmcnt wait at
+// the top of the step; nobody reads the chunk before the next chunk's first barrier), one 16-byte chunk per lane: ds_read_b128, 8 x
+// (sub, mul, max), pack, ds_write_b128 behind the first half of the step's 32 MFMAs.  (The first form rewrote the whole chunk at the
+// top of the chunk's last step - a burst of 6 such items per thread with all 8 waves on the VALU and the LDS write path at once:
+// +27 us per launch, slower than the apply pass it replaced.)  (mean, rstd) of the (at most NTB)
+// images whose tiles this block walks are copied from the norm's statistics tensor into an LDS table behind the two regions at the
+// head of the launch.  Optionally the normalised activations of the tile's OWN pixels are also stored to d.nrm_h by the blocks of
+// the first channel tile (the backward pass needs them as the weight-gradient operand): a write without the apply pass's read,
+// hidden behind the MFMAs.  Same arithmetic as in_apply_fwd_kernel ((x - mean) * rstd, act, one rounding): bitwise the two-launch
+// result.
+template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false, bool MIRROR = false, bool NORM = false>
 __global__ __launch_bounds__(512, 2)
 void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, const float* __restrict__ bias1, T* __restrict__ y,
                           const StripDesc d) {
@@ -55,6 +69,8 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
     static_assert(CAP % 8 == 0 && PIECES <= NTAPS * NW, "one strip piece per wave per K-step");
     static_assert(!XPREF || (CAP * 128) % SCRW + 1024 <= SCRW, "zero row must lie inside one wave's scratch");
     static_assert(!MIRROR || (sizeof(T) == 2 && SWZ == 1 && XPREF && 6 * 64 + 48 <= CAP && 5 * 64 + 48 + 72 <= CAP), "mirror pixels: bf16, 64-wide maps");
+    static_assert(!NORM || (sizeof(T) == 2 && SWZ == 1 && XPREF && !MIRROR), "norm strip: bf16 forward launches");
+    constexpr int NTB = 4;                        // NORM: images (= tiles) per block whose (mean, rstd) fit the LDS table (host-checked)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
 
@@ -97,6 +113,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
             *reinterpret_cast<u32x4_t*>(smem + (i >> 6) * REG + CAP * 128 + (i & 63) * 16) = u32x4_t{0u, 0u, 0u, 0u};
     };
     zero_rows();
+    [[maybe_unused]] float* ntab = reinterpret_cast<float*>(smem + 2 * REG);      // NORM: [NTB][Cin][2] (mean, rstd)
 
     // ---- strip DMA: piece j = strip rows 8j..8j+7; lane L -> row 8j + L/8, physical slot L%8 holding chunk (L%8 - (row & 6)) & 7
     const unsigned svl = (unsigned)((l8 * Cin + (SWZ ? ((ls - (l8 & 6)) & 7) : (ls ^ (l8 >> 1))) * E) * (int)sizeof(T));
@@ -174,6 +191,44 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
             }
         }
     };
+
+    // ---- NORM: (x - mean) * rstd, activation, one rounding - on ONE strip piece (8 rows x 128 B = one 16-byte chunk per lane), in place,
+    //      by the wave that DMA'd it (its own vmcnt(0) wait orders the landed piece before these reads: no barrier needed).  Lane L holds
+    //      row 8j + L/8, physical slot L%8 = channel chunk (L%8 - (row & 6)) & 7 of the 64-channel K chunk cc: the same chunk for every
+    //      piece, so a lane's 8 (mean, rstd) pairs are four 16-byte reads of the LDS table.
+    auto fix_piece = [&](int region, int j, const Tile& t, int tslot, int cc) {
+        if constexpr (NORM) {
+            const int r = 8 * j + l8;
+            const int k = (ls - (l8 & 6)) & 7;
+            u32x4_t* p = reinterpret_cast<u32x4_t*>(smem + region * REG + j * 1024 + lane * 16);
+            const float* tb = ntab + ((long)tslot * Cin + cc * BK + k * 8) * 2;
+            float f[8];
+            chunk_to_f32<T>(*p, f);
+            const int act = d.nrm_act; const float slope = d.nrm_slope;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const f32x4_t t4 = *reinterpret_cast<const f32x4_t*>(tb + 2 * e);
+                const float v0 = (f[e] - t4[0]) * t4[1], v1 = (f[e + 1] - t4[2]) * t4[3];
+                f[e] = act == UIG_ACT_RELU ? (v0 > 0.f ? v0 : 0.f) : (act == UIG_ACT_LRELU ? (v0 > 0.f ? v0 : v0 * slope) : v0);
+                f[e + 1] = act == UIG_ACT_RELU ? (v1 > 0.f ? v1 : 0.f) : (act == UIG_ACT_LRELU ? (v1 > 0.f ? v1 : v1 * slope) : v1);
+            }
+            const u32x4_t o = f32_to_chunk<T>(f);
+            if (r < t.NS) *p = o;                                                     // rows past the strip stay the DMA's zeros
+            const int pix = t.lo * d.W + r;                                            // the tile's own pixels also go to h (first channel tile only)
+            if (d.nrm_h != nullptr && t.n_base == 0 && r < t.NS && pix >= t.p0 && pix < min(t.p0 + BM, HoWo))
+                *reinterpret_cast<u32x4_t*>(static_cast<T*>(d.nrm_h) + ((long)t.img * d.H * d.W + pix) * Cin + cc * BK + k * 8) = o;
+        }
+    };
+    if constexpr (NORM) {
+        // (mean, rstd) of every image this block will touch -> LDS (plain loads now, before any DMA is in flight: a VGPR-destination
+        // load inside the K loop would make the compiler drain the DMAs in front of its use)
+        for (int rr = 0; rr < NTB; ++rr) {
+            const Tile tt = get_tile(rr);
+            if (!tt.valid) break;                                      // block-uniform
+            const float* sp = d.nrm_stats + (long)tt.img * Cin * 2;
+            for (int c = tid; c < Cin * 2; c += 64 * NW) ntab[(long)rr * Cin * 2 + c] = sp[c];
+        }
+    }
 
     unsigned long long tstamp[8];
     int nst = 0;
@@ -270,6 +325,12 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                 mirror_fix(0, cur);
             }
         }
+        if constexpr (NORM) {
+            if (r == 0) {                                                          // the block's first chunk: every wave normalises the pieces it issued itself
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (int j = wave; 8 * j < cur.NS; j += NW) fix_piece(0, j, cur, 0, 0);
+            }
+        }
         const float* bias = cur.g2 ? d.bias2 : bias1;
 
         f32x4_t acc[NT][MT];
@@ -312,6 +373,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                     // barrier: +2.5k cycles per tile by the stamps), and are published by the next step's barrier
                     if (last_t && s_on && !(d.mirror & 2)) mirror_fix(pc ^ 1, last_cc ? nxt : cur);
                 }
+
                 const unsigned char* sw = smem + (pc ^ (t & 1)) * REG + SBUF + (wn * WN + l16) * 128;
                 if constexpr (DM == 5) {
                     // the strip chunk is resident for all nine steps: only the WEIGHT fragments need this step's barrier.  The strip
@@ -323,7 +385,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                         const int co = ((q + 4 * h) ^ wswz) << 4;
 #pragma unroll
                         for (int a = 0; a < NT; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(sw + a * 16 * 128 + co);
-                        if (h == 0 && !(t == 0 && (MIRROR || cc == 0))) {
+                        if (h == 0 && !(t == 0 && (MIRROR || NORM || cc == 0))) {
 #pragma unroll
                             for (int b = 0; b < MT; ++b) xf[b] = xn[b];
                         } else {
@@ -334,11 +396,20 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                         for (int a = 0; a < NT; ++a)
 #pragma unroll
                             for (int b = 0; b < MT; ++b) MmaS<T>::run(wf[a], xf[b], acc[a][b]);
+                        if constexpr (NORM) {
+                            // behind the first half's MFMAs: this wave normalises the strip piece it DMA'd in the PREVIOUS step (landed: the
+                            // wait at the top of this step) - one 16-byte chunk per lane and step, spread over the chunk's steps 1..7
+                            if (h == 0 && t >= 1) {
+                                const int pslot = (t - 1) * NW + wave;
+                                if (s_on && pslot < PIECES && 8 * pslot < s_NS)
+                                    fix_piece(pc ^ 1, pslot, last_cc ? nxt : cur, last_cc ? r + 1 : r, last_cc ? 0 : cc + 1);
+                            }
+                        }
                     }
                     if (!last_t) {
 #pragma unroll
                         for (int b = 0; b < MT; ++b) xn[b] = *reinterpret_cast<const u32x4_t*>(sx + (unsigned)rt[(t + 1) % NTAPS][b]);
-                    } else if (!MIRROR && !last_cc) {          // the next chunk's strip is complete since step 7's barrier (mirror kernel: its
+                    } else if (!MIRROR && !NORM && !last_cc) { // the next chunk's strip is complete since step 7's barrier (mirror / norm kernel: its
                                                                // mirror pixels are only published by the NEXT barrier - fresh reads there)
                         const unsigned char* sxn = smem + (pc ^ 1) * REG;
 #pragma unroll
@@ -445,10 +516,10 @@ static int device_cus() {
     return n;
 }
 
-template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false, bool MIRROR = false>
+template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false, bool MIRROR = false, bool NORM = false>
 static int launch_pk(const void* x, const void* wp, const float* bias, void* y, const StripDesc& d, int ntiles, hipStream_t s) {
-    const size_t smem = 2 * ((size_t)(CAP + 8) * 128 + 128 * 128);
-    auto kern = conv_strip_pk_kernel<T, CAP, DM, SWZ, LGK, STAMP, MIRROR>;
+    const size_t smem = 2 * ((size_t)(CAP + 8) * 128 + 128 * 128) + (NORM ? (size_t)4 * 256 * 8 : 0);      // NORM: (mean, rstd) of 4 images x <= 256 channels
+    auto kern = conv_strip_pk_kernel<T, CAP, DM, SWZ, LGK, STAMP, MIRROR, NORM>;
     static SmemAttrOnce attr_once;
     {
         hipError_t e = attr_once.ensure(reinterpret_cast<const void*>(kern), smem);
@@ -473,6 +544,10 @@ int uig_launch_strip_pk(const void* x, const void* wp, const float* bias, void* 
     d.wo_magic = ((1 << 20) + d.Wo - 1) / d.Wo;             // (pr * magic) >> 20 == pr / Wo for pr < Wo + 256 <= 768 (pr * (magic * Wo - 2^20) < 2^20)
     const int tpi = (d.Ho * d.Wo + 255) / 256;
     const int ntiles = d.B * tpi * (d.Nrows / 128);
+    if (d.nrm_stats != nullptr) {     // the launch applies the InstanceNorm in front of it to its own input strip (uig_strip_pk_norm_ok)
+        if (dtype != UIG_BF16 || d.mirror) return uig_set_error(-1, "conv_strip_pk: the norm strip is a bf16 forward path");
+        return launch_pk<bf16_t, 448, 5, 1, true, false, false, true>(x, wp, bias, y, d, ntiles, s);
+    }
     if (dtype == UIG_BF16) {
         if (d.mirror) return d.dbg != nullptr ? launch_pk<bf16_t, 448, 0, 1, true, true, true>(x, wp, bias, y, d, ntiles, s)
                                               : (g_pk_dm == 12 ? launch_pk<bf16_t, 448, 0, 1, true, false, true>(x, wp, bias, y, d, ntiles, s)
@@ -506,4 +581,15 @@ bool uig_strip_pk_mirror_ok(const StripDesc& d, int dtype) {
     }
     for (auto& r : seen) for (bool b : r) if (!b) return false;
     return true;
+}
+
+// 1 if a launch that uig_strip_pk_ok accepts can also apply the InstanceNorm in front of it to its own input strip (StripDesc::nrm_*):
+// bf16, input and output maps of the same size, at most 256 input channels and at most 4 tiles per persistent block (the LDS table of
+// (mean, rstd) holds 4 images), no border / residual terms.
+bool uig_strip_pk_norm_ok(const StripDesc& d, int dtype) {
+    if (dtype != UIG_BF16 || d.H != d.Ho || d.W != d.Wo || d.Cin > 256 || d.border_add != nullptr || d.res_add != nullptr || d.mirror) return false;
+    const int tpi = (d.Ho * d.Wo + 255) / 256;
+    const long ntiles = (long)d.B * tpi * (d.Nrows / 128);
+    const int grid = (int)std::min<long>(ntiles, g_pk_grid > 0 ? g_pk_grid : device_cus());
+    return (ntiles + grid - 1) / grid <= 4;
 }

@@ -365,6 +365,15 @@ extern "C" int uig_instnorm_act_fwd_pre(const void* x, const void* residual, voi
     return 0;
 }
 
+// the finalize launch alone: epilogue partials of uig_conv_gather_ex (nslab per image) -> stats (mean, rstd) fp32[B][C][2]; for a
+// consumer that applies the norm itself (uig_conv3x3_innorm_fwd)
+extern "C" int uig_instnorm_finalize(const float* partial, int nslab, float* stats, int B, int64_t HW, int C, float eps, void* stream) {
+    UIG_CHECK_ARG(partial && stats && nslab > 0 && B > 0 && C > 0 && HW > 0, "uig_instnorm_finalize: bad arguments");
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, stats, B * C, C, nslab, 1.0 / (double)HW, eps, 0, 0, 0);
+    UIG_LAUNCH_CHECK("uig_instnorm_finalize");
+    return 0;
+}
+
 extern "C" int uig_instnorm_act_bwd(const void* dy, const void* x, const float* stats, void* dx, float* workspace,
                                     int B, int64_t HW, int C, int act, float slope, int dtype, void* stream) {
     return instnorm_bwd_impl(dy, x, stats, dx, workspace, nullptr, B, HW, C, act, slope, dtype, stream);

@@ -41,6 +41,10 @@ SIGNATURES = {
     "uig_reflect3x3_dgrad_mirror": (_i, [_vp, _vp, _vp, _i, _vp, _vp] + [_i] * 7 + [_vp]),
     "uig_conv_strip_applicable": (_i, [_i] * 10),
     "uig_conv_strip_tile": (_i, [_i] * 10),
+    "uig_conv3x3_innorm_applicable": (_i, [_i] * 8),
+    "uig_conv3x3_innorm_fwd": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp] + [_i] * 7 + [_i, _f, _i, _vp]),
+    "uig_debug_set_normconv": (None, [_i]),
+    "uig_instnorm_finalize": (_i, [_vp, _i, _vp, _i, _i64, _i, _f, _vp]),
     "uig_conv3x3_mx_fp8_applicable": (_i, [_i] * 5),
     "uig_conv3x3_mx_fp8": (_i, [_vp] * 8 + [_i] + [_vp] * 4 + [_i] * 8 + [_i, _f] + [_vp, _vp, _i, _f, _vp] + [_vp]),
     "uig_mx_quantize": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),

@@ -124,8 +124,12 @@ class ResBlock(nn.Module):
     def forward(self, x):
         # the skip path's gradient is summed into the first conv's input-gradient launch (ops.SkipLink), not by autograd
         link = ops.SkipLink() if (x.requires_grad and torch.is_grad_enabled()) else None
-        h = self.b[2](self.b[1](x, skip_link=link))
-        return self.b[6](self.b[5](h), residual=x, skip_link=link)
+        c1 = self.b[1](x, skip_link=link)
+        if not (self.b[2].mx_fwd or self.b[2].mx_bwd) and ops.norm_conv_applicable(c1, (self.b[5],)):
+            c2 = ops.norm_conv(c1, self.b[2], self.b[5])       # conv2 normalises its own input strip: no apply pass in between
+        else:
+            c2 = self.b[5](self.b[2](c1))
+        return self.b[6](c2, residual=x, skip_link=link)
 
 
 class _PhysNet(nn.Sequential):
@@ -266,8 +270,12 @@ def pair_forward_phys(net1: _PhysNet, net2: _PhysNet, x: torch.Tensor, taps: dic
             x = conv(m1, m2, x)
         elif isinstance(m1, ResBlock):
             link = ops.SkipLink() if (x.requires_grad and torch.is_grad_enabled()) else None
-            h = m1.b[2](conv(m1.b[1], m2.b[1], x, link))
-            x = m1.b[6](conv(m1.b[5], m2.b[5], h), residual=x, skip_link=link)
+            c1 = conv(m1.b[1], m2.b[1], x, link)
+            if not (m1.b[2].mx_fwd or m1.b[2].mx_bwd) and ops.norm_conv_applicable(c1, (m1.b[5], m2.b[5])):
+                c2 = ops.norm_conv(c1, m1.b[2], m1.b[5], m2.b[5], g)
+            else:
+                c2 = conv(m1.b[5], m2.b[5], m1.b[2](c1))
+            x = m1.b[6](c2, residual=x, skip_link=link)
         else:                      # InstNormAct / _Slot: no parameters, per-sample
             x = m1(x)
     return x

@@ -31,6 +31,8 @@ PARALLEL_BACKWARD = os.environ.get("UIG_PARALLEL_BACKWARD", "0") != "0"
 # convolution's critical path, while the stand-alone pass is HBM-bound at full occupancy.  Tested opt-in (test_ops_gpu.py).
 FUSE_BWD_STATS = os.environ.get("UIG_FUSE_BWD_STATS", "0") != "0"
 FUSE_MX_QUANT = os.environ.get("UIG_FUSE_MX_QUANT", "1") != "0"            # fp8 path: MX quantisation of activations / gradients inside the InstanceNorm launches
+# ResBlock: conv2 applies the InstanceNorm + ReLU in front of it to its own input strip (NormConvFn): no apply pass between the block's two convolutions
+NORM_CONV = os.environ.get("UIG_NORM_CONV", "0") != "0"      # OFF by default: measured slower (13.64 vs 13.48 ms per step; g_fwd 2.45 vs 2.34 ms) - see DESIGN.md
 COMBINE_PASS_WGRAD = os.environ.get("UIG_COMBINE_PASS_WGRAD", "1") != "0"  # one weight-gradient launch per ResBlock conv pair for BOTH generator passes of a step
 _SIDE_STREAMS = {}
 _DEFER_JOIN = {}
@@ -901,6 +903,86 @@ def instnorm_backward(dy, x, stats, act, slope, emit_mx=False):
                                                 _dt(x), _stream()), "uig_instnorm_act_bwd_colsum")
     dx._uig_colsum = (cpart, slabs // B, C)
     return dx
+
+
+# ----------------------------------------------------------------------------------------- conv that applies the norm in front of it
+def norm_conv_applicable(c1: torch.Tensor, layers) -> bool:
+    """can `layers` (one ConvLayer, or the same layer of two networks) consume the RAW convolution output c1 and apply the
+    InstanceNorm(+act) in front of them themselves (NormConvFn)?  c1 must carry its norm's statistics partials (`_uig_in_partial`)."""
+    pre = getattr(c1, "_uig_in_partial", None)
+    if not NORM_CONV or pre is None or c1.dtype != torch.bfloat16 or not c1.is_contiguous():
+        return False
+    spec = layers[0].spec
+    B, H, W, C = c1.shape
+    if pre[0].numel() != B * pre[1] * C * 2 or any(l.fp8 or l.spec.__dict__ != spec.__dict__ for l in layers):
+        return False
+    if not (spec.kind == "conv" and spec.k == 3 and spec.stride == 1 and spec.pad == 1 and C == spec.cin_p == spec.cin and spec.cout_store == spec.cout):
+        return False
+    pm = L.PAD_REFLECT if spec.reflect else L.PAD_ZERO
+    return L.lib().uig_conv3x3_innorm_applicable(B, H, W, C, spec.cout, pm, spec.cout_store, L.BF16) == 1
+
+
+class _BwdShim:
+    """what _conv_backward reads from an autograd ctx, for a convolution that lives inside a composite Function"""
+
+    def __init__(self, x, needs, in_hw):
+        self.saved_tensors, self.needs_input_grad, self.in_hw, self.skip_link, self.bst = (x, None), needs, in_hw, None, None
+
+
+class NormConvFn(Function):
+    """c2 = conv(act(InstanceNorm(c1))) with the norm applied by the convolution launch itself (uig_conv3x3_innorm_fwd): the second
+    convolution of a ResBlock reads the first one's raw output and normalises its own input strip in LDS - the norm's apply pass
+    (one read and one write of the whole tensor) is gone; its finalize launch (conv1's epilogue partials -> (mean, rstd)) stays.
+    When a backward pass follows, the launch also stores the normalised activations h (the weight-gradient operand: a write hidden
+    behind the MFMAs instead of a read + write pass).  One or two networks (paired launch).
+    Backward = the convolution's ordinary backward on (h, dy) followed by the norm's ordinary backward on (c1, stats): the same
+    kernels on bitwise the same tensors as the path with the apply pass."""
+
+    @staticmethod
+    def forward(ctx, c1, n_act, n_slope, n_eps, w1, b1, w2, b2, layer1, layer2, group):
+        layers = (layer1,) if layer2 is None else (layer1, layer2)
+        spec = layer1.spec
+        B, H, W, C = c1.shape
+        lib = L.lib()
+        need_bwd = any(ctx.needs_input_grad)
+        part1, nslab1 = c1._uig_in_partial
+        stats = torch.empty((B, C, 2), device=c1.device, dtype=torch.float32)
+        L.check(lib.uig_instnorm_finalize(_p(part1), nslab1, _p(stats), B, H * W, C, n_eps, _stream()), "uig_instnorm_finalize")
+        h = torch.empty_like(c1) if need_bwd else None
+        y = torch.empty((B, H, W, spec.cout_store), device=c1.device, dtype=c1.dtype)
+        part = None
+        if layer1.emit_in_stats and in_stats_fusable(spec, H, W, B, c1.dtype):
+            part = torch.empty((B * (H * W // 64) * spec.cout_store * 2,), device=c1.device, dtype=torch.float32)
+        L.check(lib.uig_conv3x3_innorm_fwd(_p(c1), _p(stats), n_act, n_slope, _p(h),
+                                           _p(layer1.wp_fwd), _p(b1), _p(layer2.wp_fwd) if layer2 is not None else None, _p(b2), group, _p(part), _p(y),
+                                           B, H, W, C, spec.cout, L.PAD_REFLECT if spec.reflect else L.PAD_ZERO, spec.cout_store, spec.act, spec.slope,
+                                           _dt(c1), _stream()), "uig_conv3x3_innorm_fwd")
+        if part is not None:
+            y._uig_in_partial = (part, H * W // 64)
+        ctx.layers, ctx.group, ctx.norm, ctx.in_hw = layers, group, (n_act, n_slope), (H, W)
+        ctx.save_for_backward(c1, stats if need_bwd else None, h)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        c1, stats, h = ctx.saved_tensors
+        layers = ctx.layers
+        ng = ctx.needs_input_grad
+        needs = (ng[0], ng[4], ng[5]) + ((ng[6], ng[7]) if len(layers) == 2 else ())
+        dh, *grads = _conv_backward(_BwdShim(h, needs, ctx.in_hw), dy, layers, ctx.group)
+        dc1 = instnorm_backward(dh.contiguous(), c1, stats, ctx.norm[0], ctx.norm[1]) if ng[0] else None
+        grads = list(grads) + [None] * (4 - len(grads))
+        return (dc1, None, None, None, grads[0], grads[1], grads[2], grads[3], None, None, None)
+
+
+def norm_conv(c1, norm, layer1, layer2=None, group=0):
+    """conv(norm(c1)) with the norm applied inside the convolution launch; `norm` = the InstNormAct module between the two
+    convolutions (act, slope, eps)"""
+    layer1.ensure_packed()
+    if layer2 is not None:
+        layer2.ensure_packed()
+        return NormConvFn.apply(c1, norm.act, norm.slope, norm.eps, layer1.weight, layer1.bias, layer2.weight, layer2.bias, layer1, layer2, group)
+    return NormConvFn.apply(c1, norm.act, norm.slope, norm.eps, layer1.weight, layer1.bias, None, None, layer1, None, 0)
 
 
 # ----------------------------------------------------------------------------------------- fused losses
