@@ -25,7 +25,11 @@ if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
     res["hbm_write_bytes"] = res["WRITE_SIZE"] * 1024
     res["hbm_bytes_per_launch"] = res["hbm_read_bytes_corrected"] + res["hbm_write_bytes"]
     res["algorithmic_bytes_per_launch"] = (16 * 64 * 64 * 256 * 2) * 2 + 2 * 256 * 2304 * 2
-res["images"], res["hw"] = 16, 64
-res["workload"] = "ResBlock conv3x3 reflect 256->256 on 64x64, paired G_A|G_B launch over 16 images, bf16 (M=65536 N=256 K=2304)"
+fp8 = bool(res.get("kernel")) and "fp8" in res["kernel"]
+res["images"], res["hw"] = (32 if fp8 else 16), 64
+res["workload"] = ("ResBlock conv3x3 reflect 256->256 on 64x64, paired G_A|G_B launch over 32 images (configs[4]: batch 8 per GPU), MX fp8 e4m3 operands (M=131072 N=256 K=2304)" if fp8
+                   else "ResBlock conv3x3 reflect 256->256 on 64x64, paired G_A|G_B launch over 16 images, bf16 (M=65536 N=256 K=2304)")
+if fp8 and "algorithmic_bytes_per_launch" in res:
+    res["algorithmic_bytes_per_launch"] = 32 * 64 * 64 * 256 * (1 + 2) + 32 * 64 * 64 * 8 + 2 * 256 * 2304
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -19,7 +19,7 @@ rm -rf $O; mkdir -p $O
 timeout -k 10 600 rocprofv3 --kernel-trace --output-format csv -d $O/t -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-other-configs > $O/log.txt 2>&1
 echo "serial trace exit code $?" | tee -a gpurun_out/${T}_exit.log
 cp $O/t/*/*_kernel_trace.csv $O/kernel_trace.csv && rm -rf $O/t
-python scripts/summarize_trace.py $O/kernel_trace.csv gpurun_out/${T}_step_serial_kernels.csv > gpurun_out/${T}_step_serial.txt 2>&1
+python scripts/summarize_trace.py $O/kernel_trace.csv gpurun_out/${T}_step_serial_kernels.csv gpurun_out/${T}_step_small_layers.csv > gpurun_out/${T}_step_serial.txt 2>&1
 rm -f $O/kernel_trace.csv
 # ---- dominant launch (as the step runs it: with the InstanceNorm statistics requested)
 D=gpurun_out/${T}_dom

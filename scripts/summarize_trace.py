@@ -34,6 +34,14 @@ for n, c, ms, us, pct in out[:28]:
 print("families:")
 for f, d in fam.most_common():
     print(f"  {f:28s} {1e-6 * d:7.3f} ms  {100.0 * d / tot:5.1f} %")
+# the gather / transposed / generic weight-gradient launches one by one, in step order (which layer costs what): name, grid, duration
+if len(sys.argv) > 3:
+    with open(sys.argv[3], "w") as fo:
+        w = csv.writer(fo); w.writerow(["order", "kernel", "grid_x", "grid_y", "grid_z", "wg_x", "lds_bytes", "us"])
+        for i, r in enumerate(win):
+            if any(k in r["n"] for k in ("igemm", "conv_tr2", "wgrad_kernel", "cin8", "headrow", "rowstrip", "gemv", "wgrad_head")):
+                w.writerow([i, r["n"], r.get("Grid_Size_X", ""), r.get("Grid_Size_Y", ""), r.get("Grid_Size_Z", ""), r.get("Workgroup_Size_X", ""),
+                            r.get("LDS_Block_Size", r.get("Group_Segment_Size", "")), round((r["e"] - r["s"]) * 1e-3, 2)])
 if len(sys.argv) > 2:
     with open(sys.argv[2], "w") as fo:
         w = csv.writer(fo); w.writerow(["kernel", "launches_per_step", "total_ms", "avg_us", "pct_of_step"])

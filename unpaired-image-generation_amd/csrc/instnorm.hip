@@ -155,12 +155,17 @@ __global__ __launch_bounds__(256) void in_apply_fwd_fin_kernel(const T* __restri
 #pragma unroll
         for (int i = 0; i < 16; ++i) { a16[i] = 0.0; q16[i] = 0.0; }
         for (int s0 = 0; s0 < np; s0 += 16) {
+            // all 16 loads of the round are issued unconditionally (clamped index) and selected afterwards: a load under a
+            // run-time condition makes the compiler branch around each one and wait for it alone - 16 dependent L2 round trips
+            // per round (guide: "register or load" trap; measured here: +7 us per launch)
+            u32x2_t v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                v[i] = *reinterpret_cast<const u32x2_t*>(partial + (((long)b * np + min(s0 + i, np - 1)) * C + c) * 2);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                if (s0 + i < np) {
-                    const float* pp = partial + (((long)b * np + s0 + i) * C + c) * 2;
-                    a16[i] += (double)pp[0]; q16[i] += (double)pp[1];
-                }
+                const bool ok = s0 + i < np;
+                a16[i] += ok ? (double)__uint_as_float(v[i][0]) : 0.0; q16[i] += ok ? (double)__uint_as_float(v[i][1]) : 0.0;
             }
         }
 #pragma unroll
@@ -429,8 +434,9 @@ extern "C" int uig_instnorm_act_fwd_infer(const void* x, const void* residual, v
         partial = workspace;
     }
     UIG_CHECK_ARG(np > 0, "uig_instnorm_act_fwd_infer: np=%d", np);
-    // fewer, fatter blocks than the training apply: every block pays the np * C * 8-byte finalize prologue
-    const int na = (int)std::max<long>(1, std::min<long>(256, HW * CC / (256 * 16)));
+    // blocks per image: every block pays the np * C * 8-byte finalize prologue (L2 reads).  Measured (scripts/bench_in_fin.py, 64x64x256,
+    // MI355X): 4 pixels per thread (the training apply's shape) is best at batch 1, 8 at batch 8 and 16; 16 is worse everywhere
+    const int na = (int)std::max<long>(1, std::min<long>(2048, HW * CC / (256 * (B <= 2 ? 4 : 8))));
     if (dtype == UIG_BF16)
         hipLaunchKernelGGL((in_apply_fwd_fin_kernel<bf16_t>), dim3(na, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, partial, np, 1.0 / (double)HW, eps, (long)HW, C, CC, na, act, slope);
     else
