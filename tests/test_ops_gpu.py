@@ -970,3 +970,44 @@ def test_norm_conv_resblock_equals_apply_pass_path(B, paired, monkeypatch):
     ref = torch.cat(outs)
     got = ops.from_nhwc(fused[0], 256).cpu()
     assert float((got - ref).abs().max()) <= 1.6e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("pm,H,W,cin,cout,B", [("reflect", 128, 128, 256, 256, 2), ("zero", 12, 128, 128, 256, 3), ("reflect", 6, 192, 128, 128, 2),
+                                                ("reflect", 16, 256, 128, 128, 1)],
+                         ids=["resblock-512sq", "zero-pad-128w", "3-segments", "4-segments"])
+def test_wgrad_row_kernel_wide_rows(pm, H, W, cin, cout, B):
+    """Round 3: the image-row weight-gradient kernel on rows wider than 64 pixels (HALO variant: a K-step is one 64-pixel segment;
+    the neighbouring segments' edge pixels - or the reflected pixel / zero at the image border - are staged as two extra rows).
+    The ResBlock maps of the 512x512 configuration (BASELINE configs[3]) are 128 wide.  Against the generic split-K kernel on the
+    same operands (2e-5 of the scale: same products, another fp32 order), against the ORACLE (bf16 tolerance), and the paired
+    (two-network) launch on uneven groups against single launches."""
+    u, ops, networks = _mods()
+    lib, dt = u.lib.lib(), torch.bfloat16
+    torch.manual_seed(H + W)
+    layer = networks.ConvLayer("conv", cin, cout, 3, 1, 1, pm, dtype=dt, device="cuda")
+    x = torch.rand(B, cin, H, W) * 2 - 1
+    dy = torch.randn(B, cout, H, W) * 0.5
+    xp, dyp = ops.to_nhwc(x.cuda(), dt), ops.to_nhwc(dy.cuda(), dt)
+    assert int(lib.uig_wgrad_splits(B, H, W, cout, H, W, cin, 3, 3, 1, 1, u.lib.BF16, 512)) == max(1, min(256 // ((cout // 128) * (cin // 128) * 3), B * H)), "the image-row kernel should take this shape"
+    try:
+        lib.uig_debug_set_wgrad_rows(2)            # 64-wide rows only: this shape on the generic kernel
+        ref = ops.conv_wgrad(layer.spec, xp, dyp)
+    finally:
+        lib.uig_debug_set_wgrad_rows(1)
+    got = ops.conv_wgrad(layer.spec, xp, dyp)
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-5 * scale, f"row kernel (wide rows) vs generic: {float((got - ref).abs().max())} of {scale}"
+    w = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    xpad = F.pad(_bf(x), (1, 1, 1, 1), mode="reflect") if pm == "reflect" else F.pad(_bf(x), (1, 1, 1, 1))
+    F.conv2d(xpad, w).backward(_bf(dy))
+    assert (got.cpu() - w.grad).abs().max() <= _tol(dt, w.grad)
+    if B >= 2:
+        g = 1
+        parts = ops.conv_wgrad_pair_partial(layer.spec, xp, dyp, g)
+        assert parts is not None
+        for sl, part in ((slice(0, g), parts[0]), (slice(g, B), parts[1])):
+            a = ops.conv_wgrad(layer.spec, xp[sl], dyp[sl], partial=part)
+            b = ops.conv_wgrad(layer.spec, xp[sl], dyp[sl])
+            torch.cuda.synchronize()
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())

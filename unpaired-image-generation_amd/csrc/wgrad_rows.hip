@@ -15,14 +15,22 @@
 // DMA writes LDS linearly, so rows are 256 B with no padding; the 16-byte chunks of row r are XOR-swizzled by 2*(r&7) on
 // the SOURCE address, which makes the ds_read_b64_tr_b16 fragment reads (8 pixel rows x 32 B per 32-lane group)
 // conflict-free.  Both MFMA operands reduce over pixels, the strided index of NHWC: the transposing read delivers them.
+//
+// Round 3, HALO: image rows wider than 64 pixels (128-wide ResBlock maps of the 512x512 configuration, BASELINE configs[3]; any
+// multiple of 64).  A K-step is then one 64-pixel SEGMENT of an image row; the kw = 0 / 2 taps of the segment's first / last pixel
+// read the neighbouring segment's edge pixel (or, at the image border, the reflected pixel / zero).  Those two pixels are staged as
+// two extra rows (64, 65) behind the X tile by ONE more DMA piece per K-step (wave 7; its counted vmcnt waits are one higher per
+// stage in flight), with the reflection / zero decision made on the scalar side per step, so the per-lane fragment address table
+// stays one table: pixel -1 -> row 64, pixel 64 -> row 65.  On 64-wide rows the original form (in-tile reflection) is kept.
 #include "uig_common.h"
 #include <algorithm>
 #include <type_traits>
 
 struct WgRowsDesc {
     int B, H, Np, Cq, pad_mode;
+    int W, S;                // image row width (a multiple of 64) and its 64-pixel segments per row; a K-step = one segment
     int ncols;               // 9 * Cq
-    int rows_total;          // B * H image rows
+    int rows_total;          // B * H * S K-steps ("rows" below = K-steps: image rows on 64-wide maps)
     int ntc, ntiles, splits; // ci tiles, tiles per network = (Np/128) * ntc * 3
     int group_rows;          // two networks in one launch: image rows [0, group_rows) are network 0's, the rest network 1's
                              // (0 = one network); partial slabs are laid out [network][split][Np][ncols]
@@ -39,15 +47,18 @@ struct WgRowsDesc {
 namespace {
 constexpr int WR_W = 64;                       // pixels per image row = pixels per K-step
 constexpr int WR_TILE = 64 * 256;              // one staged operand tile: 64 pixel rows x 128 channels bf16
-constexpr int WR_STAGE = 2 * WR_TILE + 256;    // dY tile | X tile | one zero row (zero padding of the X columns)
 constexpr int WR_NST = 4;
+constexpr int wr_xtile(bool halo) { return halo ? 68 * 256 : WR_TILE; }             // HALO: + rows 64 (left neighbour), 65 (right), 66-67 unused
+constexpr int wr_stage(bool halo) { return WR_TILE + wr_xtile(halo) + 256; }        // dY tile | X tile | one zero row (zero padding of the X columns)
 }
 
+template <bool HALO>
 __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __restrict__ P, const bf16_t* __restrict__ Q,
                                                                const bf16_t* __restrict__ P2, const bf16_t* __restrict__ Q2,
                                                                float* __restrict__ part, const WgRowsDesc d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
+    constexpr int WR_STAGE = wr_stage(HALO), XT0 = WR_TILE, ZROW = WR_TILE + wr_xtile(HALO);      // stage-relative offsets: X tile, zero row
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -69,7 +80,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
     const int nk = row_end - row_begin;
 
     // zero rows (one per stage)
-    if (tid < WR_NST * 16) *reinterpret_cast<u32x4_t*>(smem + (tid >> 4) * WR_STAGE + 2 * WR_TILE + (tid & 15) * 16) = u32x4_t{0u, 0u, 0u, 0u};
+    if (tid < WR_NST * 16) *reinterpret_cast<u32x4_t*>(smem + (tid >> 4) * WR_STAGE + ZROW + (tid & 15) * 16) = u32x4_t{0u, 0u, 0u, 0u};
 
     // ---- DMA: wave w stages pieces w and w+8 (rows 4w..4w+3 and +32) of both tiles
     const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(P), 0, d.p_bytes, 0x00020000);
@@ -81,40 +92,60 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
     const unsigned voffP = (unsigned)((ra * d.Np + n_base + chunk * 8) * 2);
     const unsigned voffQ = (unsigned)((ra * d.Cq + ci_base + chunk * 8) * 2);
     const bool refl = d.pad_mode == UIG_PAD_REFLECT;
-    // (tensor, image, row) of the next K-step to issue: the network's rows are run 2*net followed by run 2*net+1 (whole images)
+    // (tensor, image, row, segment) of the next K-step to issue: the network's steps are run 2*net followed by run 2*net+1 (whole images)
     const int run_a = 2 * net, a_rows = d.run_rows[run_a];
-    const int l0 = row_begin - net_row0;                              // row inside the network
+    const int HS = d.H * d.S;                                         // K-steps per image
+    const int l0 = row_begin - net_row0;                              // step inside the network
     const bool in_a = l0 < a_rows;
     const int loc0 = in_a ? l0 : l0 - a_rows;
     int sel = d.run_sel[in_a ? run_a : run_a + 1];
-    int ib = d.run_img0[in_a ? run_a : run_a + 1] + loc0 / d.H, ii = loc0 % d.H;
-    int left = in_a ? a_rows - l0 : 0x7fffffff;                      // rows until the switch to the second run
+    int ib = d.run_img0[in_a ? run_a : run_a + 1] + loc0 / HS, ii = (loc0 % HS) / d.S, sg = (loc0 % HS) % d.S;
+    int left = in_a ? a_rows - l0 : 0x7fffffff;                      // steps until the switch to the second run
     const int nx_sel = d.run_sel[run_a + 1], nx_img0 = d.run_img0[run_a + 1];
+    // HALO: the extra piece (rows 64, 65 of the X tile): lanes 0-15 the left neighbour pixel, 16-31 the right one, the rest nothing
+    const int hq = lane >> 4;
+    const unsigned hchunk = (unsigned)(((lane & 15) ^ ((hq & 7) << 1)) * 16 + ci_base * 2);   // row 64 + hq: swizzle by 2 * ((64 + hq) & 7) = 2 * hq
     auto issue = [&](int stage) {
         const int hi = ii + kh - 1;
         const bool valid = refl | ((unsigned)hi < (unsigned)d.H);
         const int hr = refl ? reflect_idx(hi, d.H) : (valid ? hi : 0);
-        const int sP = __builtin_amdgcn_readfirstlane((int)((unsigned)(ib * d.H + ii) * (unsigned)(WR_W * 2) * (unsigned)d.Np));
-        const int sQ = __builtin_amdgcn_readfirstlane((int)((unsigned)(ib * d.H + hr) * (unsigned)(WR_W * 2) * (unsigned)d.Cq));
+        const int sP = __builtin_amdgcn_readfirstlane((int)(((unsigned)(ib * d.H + ii) * (unsigned)d.W + (unsigned)(sg * WR_W)) * 2u * (unsigned)d.Np));
+        const int sQ = __builtin_amdgcn_readfirstlane((int)(((unsigned)(ib * d.H + hr) * (unsigned)d.W + (unsigned)(sg * WR_W)) * 2u * (unsigned)d.Cq));
         const unsigned vq = valid ? voffQ : 0xFFFFFFFFu;              // zero-padded row: out-of-range offset -> zeros
         lds_ptr_t dst = (lds_ptr_t)smem + stage * WR_STAGE + wave * 1024;
         if (__builtin_amdgcn_readfirstlane(sel) == 0) {               // block-uniform
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (__attribute__((address_space(3))) void*)dst, 16, (int)voffP, sP, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (__attribute__((address_space(3))) void*)(dst + 8192), 16, (int)voffP,
                                                      sP + 32 * d.Np * 2, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(dst + WR_TILE), 16, (int)vq, sQ, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(dst + WR_TILE + 8192), 16, (int)vq,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(dst + XT0), 16, (int)vq, sQ, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(dst + XT0 + 8192), 16, (int)vq,
                                                      sQ + 32 * d.Cq * 2, 0, 0);
         } else {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP2, (__attribute__((address_space(3))) void*)dst, 16, (int)voffP, sP, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP2, (__attribute__((address_space(3))) void*)(dst + 8192), 16, (int)voffP,
                                                      sP + 32 * d.Np * 2, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ2, (__attribute__((address_space(3))) void*)(dst + WR_TILE), 16, (int)vq, sQ, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ2, (__attribute__((address_space(3))) void*)(dst + WR_TILE + 8192), 16, (int)vq,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ2, (__attribute__((address_space(3))) void*)(dst + XT0), 16, (int)vq, sQ, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ2, (__attribute__((address_space(3))) void*)(dst + XT0 + 8192), 16, (int)vq,
                                                      sQ + 32 * d.Cq * 2, 0, 0);
         }
-        if (++ii == d.H) { ii = 0; ++ib; }
-        if (--left == 0) { sel = nx_sel; ib = nx_img0; ii = 0; left = 0x7fffffff; }
+        if constexpr (HALO) {
+            if (wave == 7) {                                          // wave-uniform: one more piece per K-step from this wave (its vmcnt counts differ)
+                // pixel left of / right of the segment inside input row hr; at the image border the reflected pixel, or nothing (zeros)
+                int lp = sg * WR_W - 1, rp = sg * WR_W + WR_W;
+                const bool lok = valid && (lp >= 0 || refl), rok = valid && (rp < d.W || refl);
+                lp = lp < 0 ? 1 : lp; rp = rp >= d.W ? d.W - 2 : rp;
+                const int sH = __builtin_amdgcn_readfirstlane((int)((unsigned)(ib * d.H + hr) * (unsigned)d.W * 2u * (unsigned)d.Cq));   // row base
+                const bool ok = hq == 0 ? lok : (hq == 1 ? rok : false);
+                const unsigned vh = ok ? hchunk + (unsigned)((hq == 0 ? lp : rp) * d.Cq * 2) : 0xFFFFFFFFu;
+                lds_ptr_t hd = (lds_ptr_t)smem + stage * WR_STAGE + XT0 + 64 * 256;
+                if (__builtin_amdgcn_readfirstlane(sel) == 0)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)hd, 16, (int)vh, sH, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ2, (__attribute__((address_space(3))) void*)hd, 16, (int)vh, sH, 0, 0);
+            }
+        }
+        if (++sg == d.S) { sg = 0; if (++ii == d.H) { ii = 0; ++ib; } }
+        if (--left == 0) { sel = nx_sel; ib = nx_img0; ii = 0; sg = 0; left = 0x7fffffff; }
     };
 
     // ---- fragment addressing (stage-relative byte offsets).  Wave (wn, wc): 64 co x 32 ci x 3 kw.
@@ -134,13 +165,14 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
         for (int gq = 0; gq < 4; ++gq) {
             const int pix = 16 * gq + k0 + kw - 1;
             const bool inb = (unsigned)pix < (unsigned)WR_W;
-            const int row = refl ? reflect_idx(pix, WR_W) : (inb ? pix : 0);
-            const bool zero = !refl && !inb;
+            // HALO: the segment's neighbours sit in rows 64 / 65 (already reflected / zeroed by the DMA that staged them)
+            const int row = HALO ? (pix < 0 ? 64 : (pix >= WR_W ? 65 : pix)) : (refl ? reflect_idx(pix, WR_W) : (inb ? pix : 0));
+            const bool zero = !HALO && !refl && !inb;
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const int cidx = wc * 4 + 2 * a + (pp >> 1);
-                qoff[kw][gq][a] = zero ? (unsigned)(2 * WR_TILE + ((cidx & 15) << 4) + (pp & 1) * 8)
-                                       : (unsigned)(WR_TILE + row * 256 + ((cidx ^ ((row & 7) << 1)) << 4) + (pp & 1) * 8);
+                qoff[kw][gq][a] = zero ? (unsigned)(ZROW + ((cidx & 15) << 4) + (pp & 1) * 8)
+                                       : (unsigned)(XT0 + row * 256 + ((cidx ^ ((row & 7) << 1)) << 4) + (pp & 1) * 8);
             }
         }
 
@@ -210,9 +242,16 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
     if (nk > 1) issue(1);
     if (nk > 2) issue(2);
     if (nk > 0) {
-        if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // stages allowed to stay in flight: 2 / 1 / 0 (4 pieces per stage from every wave; 5 from wave 7 with HALO)
+        if (HALO && wave == 7) {
+            if (nk > 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (nk > 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int c = 0; c < 5; ++c) read_chunk(bf0, af0, lds0, std::integral_constant<int, 0>{}, c);
@@ -234,8 +273,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
 #ifdef UIG_X_STAMP
             const unsigned long long w0 = __builtin_amdgcn_s_memtime();
 #endif
-            if (ks + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // stage ks+1 landed; stage ks+2 may still fly
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ks + 2 < nk) {                                                      // stage ks+1 landed; stage ks+2 may still fly
+                if (HALO && wave == 7) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef UIG_X_STAMP
             const unsigned long long w1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -291,7 +332,7 @@ extern "C" void uig_debug_set_wgrad_rows(int on) { g_wgrad_rows = on; }
 // 1 if uig_wgrad_partial runs this launch on the row kernel
 bool uig_wgrad_rows_applicable(int Mh, int Mw, int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int dtype) {
     return g_wgrad_rows && dtype == UIG_BF16 && kH == 3 && kW == 3 && stride == 1 && pad == 1 && Mh == Hq && Mw == Wq &&
-           Mw == WR_W && Np % 128 == 0 && Cq % 128 == 0 && Hq >= 2;
+           Mw % WR_W == 0 && Mw <= 1024 && (g_wgrad_rows != 2 || Mw == WR_W) && Np % 128 == 0 && Cq % 128 == 0 && Hq >= 2;      // hook value 2: 64-wide rows only (A/B)
 }
 
 int uig_wgrad_rows_tiles(int Np, int Cq) { return (Np / 128) * (Cq / 128) * 3; }
@@ -299,32 +340,38 @@ int uig_wgrad_rows_tiles(int Np, int Cq) { return (Np / 128) * (Cq / 128) * 3; }
 // General form: up to two runs of whole images per network, each in (P, Q) [sel 0] or (P2, Q2) [sel 1]; imgs[r] images starting
 // at image img0[r] of its tensor; runs 0, 1 are network 0's, runs 2, 3 network 1's (one network: runs 2, 3 empty).
 // B1 / B2 = images in (P, Q) / (P2, Q2) (for the range checks of the buffer descriptors).
-int uig_launch_wgrad_rows_runs(const void* P, const void* Q, const void* P2, const void* Q2, float* ws, int B1, int B2, int H, int Np, int Cq,
+int uig_launch_wgrad_rows_runs(const void* P, const void* Q, const void* P2, const void* Q2, float* ws, int B1, int B2, int H, int W, int Np, int Cq,
                                int pad_mode, int splits, const int* imgs, const int* img0, const int* sel, hipStream_t s) {
     WgRowsDesc d{};
     int total = 0;
-    for (int r = 0; r < 4; ++r) { d.run_rows[r] = imgs[r] * H; d.run_img0[r] = img0[r]; d.run_sel[r] = sel[r]; total += imgs[r]; }
+    const int S = W / WR_W;
+    d.W = W; d.S = S;
+    for (int r = 0; r < 4; ++r) { d.run_rows[r] = imgs[r] * H * S; d.run_img0[r] = img0[r]; d.run_sel[r] = sel[r]; total += imgs[r]; }
     const bool two = imgs[2] + imgs[3] > 0;
     d.group_rows = two ? d.run_rows[0] + d.run_rows[1] : 0;
-    d.B = total; d.H = H; d.Np = Np; d.Cq = Cq; d.pad_mode = pad_mode; d.ncols = 9 * Cq; d.rows_total = total * H;
+    d.B = total; d.H = H; d.Np = Np; d.Cq = Cq; d.pad_mode = pad_mode; d.ncols = 9 * Cq; d.rows_total = total * H * S;
     d.ntc = Cq / 128; d.ntiles = uig_wgrad_rows_tiles(Np, Cq); d.splits = splits;
-    d.p_bytes = (unsigned)((long)B1 * H * WR_W * Np * 2); d.q_bytes = (unsigned)((long)B1 * H * WR_W * Cq * 2);
-    d.p2_bytes = (unsigned)((long)B2 * H * WR_W * Np * 2); d.q2_bytes = (unsigned)((long)B2 * H * WR_W * Cq * 2);
-    const size_t smem = (size_t)WR_NST * WR_STAGE;
-    static SmemAttrOnce attr_once;
+    d.p_bytes = (unsigned)((long)B1 * H * W * Np * 2); d.q_bytes = (unsigned)((long)B1 * H * W * Cq * 2);
+    d.p2_bytes = (unsigned)((long)B2 * H * W * Np * 2); d.q2_bytes = (unsigned)((long)B2 * H * W * Cq * 2);
+    if ((long)std::max(B1, B2) * H * W * std::max(Np, Cq) * 2 >= (1L << 32) - 64) return uig_set_error(-1, "wgrad(rows): operand larger than 4 GiB");
+    const bool halo = S > 1;
+    const size_t smem = (size_t)WR_NST * wr_stage(halo);
+    static SmemAttrOnce attr0, attr1;
     {
-        hipError_t e = attr_once.ensure(reinterpret_cast<const void*>(wgrad_rows3_kernel), (size_t)(int)smem);
+        hipError_t e = halo ? attr1.ensure(reinterpret_cast<const void*>(wgrad_rows3_kernel<true>), smem)
+                            : attr0.ensure(reinterpret_cast<const void*>(wgrad_rows3_kernel<false>), smem);
         if (e != hipSuccess) return uig_set_error((int)e, "wgrad(rows): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(wgrad_rows3_kernel, dim3(d.ntiles * splits * (two ? 2 : 1)), dim3(512), smem, s, (const bf16_t*)P, (const bf16_t*)Q,
-                       (const bf16_t*)P2, (const bf16_t*)Q2, ws, d);
+    const dim3 grid(d.ntiles * splits * (two ? 2 : 1));
+    if (halo) hipLaunchKernelGGL(wgrad_rows3_kernel<true>, grid, dim3(512), smem, s, (const bf16_t*)P, (const bf16_t*)Q, (const bf16_t*)P2, (const bf16_t*)Q2, ws, d);
+    else hipLaunchKernelGGL(wgrad_rows3_kernel<false>, grid, dim3(512), smem, s, (const bf16_t*)P, (const bf16_t*)Q, (const bf16_t*)P2, (const bf16_t*)Q2, ws, d);
     UIG_LAUNCH_CHECK("uig_wgrad_partial(rows)");
     return 0;
 }
 
-int uig_launch_wgrad_rows(const void* P, const void* Q, float* ws, int B, int H, int Np, int Cq, int pad_mode, int splits,
+int uig_launch_wgrad_rows(const void* P, const void* Q, float* ws, int B, int H, int W, int Np, int Cq, int pad_mode, int splits,
                           int group_images, hipStream_t s) {
     const int imgs[4] = {group_images > 0 ? group_images : B, 0, group_images > 0 ? B - group_images : 0, 0};
     const int img0[4] = {0, 0, group_images, 0}, sel[4] = {0, 0, 0, 0};
-    return uig_launch_wgrad_rows_runs(P, Q, nullptr, nullptr, ws, B, 0, H, Np, Cq, pad_mode, splits, imgs, img0, sel, s);
+    return uig_launch_wgrad_rows_runs(P, Q, nullptr, nullptr, ws, B, 0, H, W, Np, Cq, pad_mode, splits, imgs, img0, sel, s);
 }
