@@ -47,6 +47,7 @@ void uig_debug_set_tile(int bn);
  * 2 = 128x128 single-buffer strip tiles, 3 = never the persistent (one block per CU, walks its tiles) 256x128 kernel.
  * All uig_debug_set_* hooks write process-global selection state: set them before launching, never concurrently with launches. */
 void uig_debug_set_strip(int on);
+void uig_debug_set_strip_wide(int on);   /* 1 (default): reflection-padded 3x3 forward convs on 128-pixel-wide maps on the persistent strip kernel (512-row strip), 0: generic kernel */
 /* tuning hook of the persistent strip kernel: dm = K-loop variant (0 default: DMA issue at the top of the K-step, the next step's
  * strip fragments read behind this step's MFMAs; 12 = without that prefetch; 2 / 4 / 8 / 9 / 10 = the rejected variants of DESIGN
  * §3.2), grid = persistent grid size (0 = one block per CU) */

@@ -1011,3 +1011,42 @@ def test_wgrad_row_kernel_wide_rows(pm, H, W, cin, cout, B):
             b = ops.conv_wgrad(layer.spec, xp[sl], dyp[sl])
             torch.cuda.synchronize()
             assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("B,group", [(2, 0), (4, 2), (3, 1)], ids=["single2", "paired4", "paired3-uneven"])
+def test_strip_persistent_512_row_strip_on_128_wide_maps(B, group):
+    """Round 3: the ResBlock FORWARD convolution of the 512x512 configuration (BASELINE configs[3]: 256 -> 256, 3x3, reflection pad 1,
+    128x128 maps) on the persistent strip kernel's no-zero-row variant (256-pixel tiles = two image rows + two halo rows = 512 strip
+    rows, 2 x 80 KB of LDS) instead of the generic gather kernel: output and fused InstanceNorm statistics against the oracle
+    (bf16 tolerance) and against the generic kernel; kernel id asserted.  Its input gradient (zero padding: needs the zero rows)
+    stays where it was."""
+    u, ops, networks = _mods()
+    lib, dt = u.lib.lib(), torch.bfloat16
+    S, C = 128, 256
+    torch.manual_seed(900 + B)
+    g = group if group else B
+    ls = [networks.ConvLayer("conv", C, C, 3, 1, 1, "reflect", dtype=dt, device="cuda") for _ in range(2 if group else 1)]
+    for l in ls:
+        with torch.no_grad():
+            l.weight.mul_(1.5); l.bias.normal_(0, 0.1)
+        l.emit_in_stats = True
+        l.ensure_packed()
+    x = torch.rand(B, C, S, S) * 2 - 1
+    xp = ops.to_nhwc(x.cuda(), dt)
+    pair = (ls[1].wp_fwd, ls[1].bias, g) if group else None
+    yp = ops.conv_forward(ls[0].spec, xp, ls[0].wp_fwd, ls[0].bias, pair=pair, want_in_stats=True)
+    assert lib.uig_debug_last_conv_kernel() == u.lib.K_STRIP_PK, "the 512-row strip variant did not take the launch"
+    try:
+        lib.uig_debug_set_strip_wide(0)
+        yg = ops.conv_forward(ls[0].spec, xp, ls[0].wp_fwd, ls[0].bias, pair=pair, want_in_stats=True)
+        assert lib.uig_debug_last_conv_kernel() == u.lib.K_IGEMM
+    finally:
+        lib.uig_debug_set_strip_wide(1)
+    parts = [(0, g, 0)] + ([(g, B, 1)] if group else [])
+    yref = torch.cat([F.conv2d(F.pad(_bf(x[a:e]), (1, 1, 1, 1), mode="reflect"), _bf(ls[i].weight.detach().cpu()), ls[i].bias.detach().cpu()) for a, e, i in parts])
+    y = ops.from_nhwc(yp, C).cpu()
+    assert (y - yref).abs().max() <= _tol(dt, yref)
+    assert float((yp.float() - yg.float()).abs().max()) <= 0.02 * float(yref.abs().max())
+    zn = ops.from_nhwc(networks.InstNormAct(u.lib.ACT_RELU)(yp), C).cpu()            # consumes the statistics partials of this launch
+    zref = F.relu(F.instance_norm(y, eps=1e-5))
+    assert (zn - zref).abs().max() <= _tol(dt, zref)

@@ -38,6 +38,7 @@ struct StripDesc {
     const float* nrm_stats;
     int nrm_act; float nrm_slope;
     void* nrm_h;
+    int wide512;             // persistent bf16 kernel: 1 = the 512-row strip without zero rows (conv_strip_pk.hip, NOZ; set by uig_try_conv_strip)
 };
 
 struct UigBst { const void* x; const float* stats; float* partial; int act; float slope; };

@@ -54,7 +54,11 @@
 // the first channel tile (the backward pass needs them as the weight-gradient operand): a write without the apply pass's read,
 // hidden behind the MFMAs.  Same arithmetic as in_apply_fwd_kernel ((x - mean) * rstd, act, one rounding): bitwise the two-launch
 // result.
-template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false, bool MIRROR = false, bool NORM = false>
+//
+// NOZ (round 3): no zero rows behind the strip - for launches that never read one (reflection padding, whole tiles): the strip may then
+// be CAP = 512 rows (2 x 80 KB of LDS exactly, 16-bit row table up to 65,520), i.e. a 256-pixel tile of a 128-pixel-wide map (two
+// image rows + two halo rows): the ResBlock forward convolutions of the 512x512 configuration on this kernel instead of the generic one.
+template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false, bool MIRROR = false, bool NORM = false, bool NOZ = false>
 __global__ __launch_bounds__(512, 2)
 void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, const float* __restrict__ bias1, T* __restrict__ y,
                           const StripDesc d) {
@@ -62,12 +66,13 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
     constexpr int BK = 8 * E;
     constexpr int BM = 256, BN = 128, NW = 8, NTAPS = 9, WM = 64, WN = 64, MT = 4, NT = 4;
     constexpr int PIECES = CAP / 8;
-    constexpr int SBUF = (CAP + 8) * 128, WSTG = BN * 128, REG = SBUF + WSTG;     // LDS: [strip 0][weights 0][strip 1][weights 1]
+    constexpr int SBUF = (CAP + (NOZ ? 0 : 8)) * 128, WSTG = BN * 128, REG = SBUF + WSTG;     // LDS: [strip 0][weights 0][strip 1][weights 1]
     constexpr int SCRW = 64 * 64 * (int)sizeof(T);                                  // one wave's epilogue scratch
     constexpr bool XPREF = NW * SCRW <= REG;      // the scratch fits the region the last K-step used: prefetch the next tile behind the last chunk
     constexpr int ZW = CAP * 128 / SCRW;          // the wave whose scratch covers the region's zero row
     static_assert(CAP % 8 == 0 && PIECES <= NTAPS * NW, "one strip piece per wave per K-step");
-    static_assert(!XPREF || (CAP * 128) % SCRW + 1024 <= SCRW, "zero row must lie inside one wave's scratch");
+    static_assert(NOZ || !XPREF || (CAP * 128) % SCRW + 1024 <= SCRW, "zero row must lie inside one wave's scratch");
+    static_assert(!NOZ || (XPREF && !MIRROR && !NORM && (CAP - 1) * 128 + 127 < 65536), "no-zero-row variant: plain forward launches, 16-bit row table");
     static_assert(!MIRROR || (sizeof(T) == 2 && SWZ == 1 && XPREF && 6 * 64 + 48 <= CAP && 5 * 64 + 48 + 72 <= CAP), "mirror pixels: bf16, 64-wide maps");
     static_assert(!NORM || (sizeof(T) == 2 && SWZ == 1 && XPREF && !MIRROR), "norm strip: bf16 forward launches");
     constexpr int NTB = 4;                        // NORM: images (= tiles) per block whose (mean, rstd) fit the LDS table (host-checked)
@@ -109,6 +114,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
         const_cast<void*>(d.wp2 != nullptr ? d.wp2 : static_cast<const void*>(wp1)), 0, d.w_bytes, 0x00020000);
 
     auto zero_rows = [&]() {                                  // rows CAP .. CAP+7 of both strip buffers
+        if constexpr (!NOZ)
         for (int i = tid; i < 2 * 64; i += 64 * NW)
             *reinterpret_cast<u32x4_t*>(smem + (i >> 6) * REG + CAP * 128 + (i & 63) * 16) = u32x4_t{0u, 0u, 0u, 0u};
     };
@@ -308,7 +314,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                 int a;
                 if constexpr (MIRROR) a = ra[i] ? TA[j] : (ca[j] ? CA[i] : A[i]) + Bj[j];
                 else a = A[i] + Bj[j];
-                rt[t][b] = (unsigned short)((hok[i] & wok[j]) ? a : Z[j]);
+                rt[t][b] = (unsigned short)((NOZ || (hok[i] & wok[j])) ? a : Z[j]);      // NOZ: host-checked that no tap leaves the image
             }
         }
     };
@@ -482,6 +488,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
         if constexpr (XPREF) {
             // the scratch covered region pl's zero row: its owner restores it (read again from the next tile's chunk 1 on,
             // many barriers from here)
+            if constexpr (!NOZ)
             if (wave == ZW) *reinterpret_cast<u32x4_t*>(smem + pl * REG + CAP * 128 + lane * 16) = u32x4_t{0u, 0u, 0u, 0u};
             par = pl ^ 1;
         } else {
@@ -516,10 +523,10 @@ static int device_cus() {
     return n;
 }
 
-template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false, bool MIRROR = false, bool NORM = false>
+template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false, bool MIRROR = false, bool NORM = false, bool NOZ = false>
 static int launch_pk(const void* x, const void* wp, const float* bias, void* y, const StripDesc& d, int ntiles, hipStream_t s) {
-    const size_t smem = 2 * ((size_t)(CAP + 8) * 128 + 128 * 128) + (NORM ? (size_t)4 * 256 * 8 : 0);      // NORM: (mean, rstd) of 4 images x <= 256 channels
-    auto kern = conv_strip_pk_kernel<T, CAP, DM, SWZ, LGK, STAMP, MIRROR, NORM>;
+    const size_t smem = 2 * ((size_t)(CAP + (NOZ ? 0 : 8)) * 128 + 128 * 128) + (NORM ? (size_t)4 * 256 * 8 : 0);      // NORM: (mean, rstd) of 4 images x <= 256 channels
+    auto kern = conv_strip_pk_kernel<T, CAP, DM, SWZ, LGK, STAMP, MIRROR, NORM, NOZ>;
     static SmemAttrOnce attr_once;
     {
         hipError_t e = attr_once.ensure(reinterpret_cast<const void*>(kern), smem);
@@ -533,8 +540,9 @@ static int launch_pk(const void* x, const void* wp, const float* bias, void* y, 
 
 // 1 if the persistent kernel can take this 256x128-tile launch (d filled by uig_try_conv_strip): taps must form a 3x3 grid
 // (dh a function of t / 3, dw of t % 3) and the in-tile division by Wo must be exact in 20-bit fixed point.
+// need256 in 449..512: only the no-zero-row variant (uig_strip_pk_wide_ok) can take it
 bool uig_strip_pk_ok(const StripDesc& d, int need256) {
-    if (need256 > 448 || d.Wo > 512 || d.W % 16 != 0) return false;      // W % 16: the row table's separable swizzle (build_rt)
+    if (need256 > 512 || d.Wo > 512 || d.W % 16 != 0) return false;      // W % 16: the row table's separable swizzle (build_rt)
     for (int t = 0; t < 9; ++t)
         if ((d.tap[t] & 255) != (d.tap[3 * (t / 3)] & 255) || ((d.tap[t] >> 8) & 255) != ((d.tap[t % 3] >> 8) & 255)) return false;
     return true;
@@ -544,6 +552,10 @@ int uig_launch_strip_pk(const void* x, const void* wp, const float* bias, void* 
     d.wo_magic = ((1 << 20) + d.Wo - 1) / d.Wo;             // (pr * magic) >> 20 == pr / Wo for pr < Wo + 256 <= 768 (pr * (magic * Wo - 2^20) < 2^20)
     const int tpi = (d.Ho * d.Wo + 255) / 256;
     const int ntiles = d.B * tpi * (d.Nrows / 128);
+    if (d.wide512) {                  // 449..512 strip rows: the no-zero-row variant (host-checked: reflection padding, whole tiles, plain forward)
+        if (dtype != UIG_BF16) return uig_set_error(-1, "conv_strip_pk: the 512-row strip is a bf16 path");
+        return launch_pk<bf16_t, 512, 5, 1, true, false, false, false, true>(x, wp, bias, y, d, ntiles, s);
+    }
     if (d.nrm_stats != nullptr) {     // the launch applies the InstanceNorm in front of it to its own input strip (uig_strip_pk_norm_ok)
         if (dtype != UIG_BF16 || d.mirror) return uig_set_error(-1, "conv_strip_pk: the norm strip is a bf16 forward path");
         return launch_pk<bf16_t, 448, 5, 1, true, false, false, true>(x, wp, bias, y, d, ntiles, s);
@@ -592,4 +604,14 @@ bool uig_strip_pk_norm_ok(const StripDesc& d, int dtype) {
     const long ntiles = (long)d.B * tpi * (d.Nrows / 128);
     const int grid = (int)std::min<long>(ntiles, g_pk_grid > 0 ? g_pk_grid : device_cus());
     return (ntiles + grid - 1) / grid <= 4;
+}
+
+// 1 if a launch whose 256-pixel tiles need 449..512 strip rows (128-pixel-wide maps: two image rows + two halo rows) can run on the
+// no-zero-row variant: bf16, reflection padding with every reflected row inside the strip, whole tiles (no pixel past the image), all
+// channels stored, no border / residual / mirror / norm terms.
+bool uig_strip_pk_wide_ok(const StripDesc& d, int dtype, int need256) {
+    if (dtype != UIG_BF16 || need256 <= 448 || need256 > 512 || d.pad_mode != UIG_PAD_REFLECT) return false;
+    if ((d.Ho * d.Wo) % 256 != 0 || d.H != d.Ho || d.W != d.Wo || d.dh_min != -1 || d.dh_max != 1) return false;
+    if (d.border_add != nullptr || d.res_add != nullptr || d.bst_partial != nullptr || d.mirror || d.nrm_stats != nullptr) return false;
+    return uig_strip_pk_ok(d, need256);
 }

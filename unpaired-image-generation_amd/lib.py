@@ -26,6 +26,7 @@ SIGNATURES = {
     "uig_debug_last_conv_kernel": (_i, []),
     "uig_debug_set_tile": (None, [_i]),
     "uig_debug_set_strip": (None, [_i]),
+    "uig_debug_set_strip_wide": (None, [_i]),
     "uig_debug_set_mirror": (None, [_i]),
     "uig_debug_set_strip_pk": (None, [_i, _i]),
     "uig_debug_set_rowstrip": (None, [_i]),
