@@ -148,8 +148,18 @@ void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned c
     __syncthreads();
     issue_first(cur, 0);
 
-    unsigned short rt[NTAPS][MT];
+    // row table: two 16-bit LDS offsets per register, unpacked at the point of use behind a compiler barrier - left to itself the
+    // optimiser hoists the 36 zero-extended offsets AND the 36 scale-dword addresses derived from them out of the chunk loop (they do
+    // not depend on the chunk): 72 registers, 20 of them spilled to scratch and re-loaded inside the K loop, one VMEM load per
+    // tap-step whose wait drains the step's LDS-DMAs (round 3: that was the kernel's 51 % SQ_WAIT_ANY)
+    unsigned rtp[NTAPS * MT / 2];
     int rt_ti = -1;
+    auto rt_get = [&](int t, int b) -> unsigned {
+        const int i = t * MT + b;
+        unsigned v = rtp[i >> 1];
+        asm volatile("" : "+v"(v));
+        return (i & 1) ? (v >> 16) : (v & 0xffffu);
+    };
     auto build_rt = [&](const Tile& tl) {
         const bool refl = d.pad_mode == UIG_PAD_REFLECT;
         const int ho0 = tl.p0 / d.Wo, rem0 = tl.p0 - ho0 * d.Wo;
@@ -173,11 +183,15 @@ void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned c
             for (int t = 0; t < NTAPS; ++t) {
                 const int s0 = hrow[t / 3] + wcol[t % 3];
                 const int s = (pv & (s0 >= 0)) ? s0 : CAP;
-                rt[t][b] = (unsigned short)(s * 128 + (((q + (s & 6)) & 7) << 4));
+                const unsigned av = (unsigned)(s * 128 + (((q + (s & 6)) & 7) << 4)) & 0xffffu;
+                const int ri = t * MT + b;
+                rtp[ri >> 1] = (ri & 1) ? ((rtp[ri >> 1] & 0xffffu) | (av << 16)) : ((rtp[ri >> 1] & 0xffff0000u) | av);
             }
         }
     };
 
+#pragma unroll
+    for (int i = 0; i < NTAPS * MT / 2; ++i) rtp[i] = 0u;
     const int wswz = (l16 >> 1) & 7;
     const int co_lo = (q ^ wswz) << 4;
     const int sh = 8 * q;                                      // this lane's K block inside a scale dword
@@ -219,15 +233,11 @@ void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned c
 
                 const unsigned char* swb = smem + (pc ^ (t & 1)) * REG + SBUF + XSB;
                 const unsigned char* sw = swb + (wn * WN + l16) * 128;
-                i32x8_t xf[MT], wf[NT];
-                int xsc[MT], wsc[NT];
-#pragma unroll
-                for (int b = 0; b < MT; ++b) {
-                    const unsigned a0 = rt[t][b];
-                    const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(sx + a0), hi = *reinterpret_cast<const u32x4_t*>(sx + (a0 ^ 64u));
-                    xf[b] = i32x8_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-                    xsc[b] = (int)(*reinterpret_cast<const unsigned*>(sx + SBUF + ((a0 >> 7) << 2)) >> sh);
-                }
+                // Round 3: the step's fragments in two halves over the pixel groups (4 weight fragments + 2 x 2 strip fragments: 48 operand
+                // registers live at once instead of 64).  With all 8 fragments loaded up front the kernel sat at 256 VGPRs with 20 of them
+                // spilled to scratch inside the K loop (84 B per lane: scratch traffic counted on the same vmcnt the step's DMA wait drains).
+                i32x8_t wf[NT];
+                int wsc[NT];
 #pragma unroll
                 for (int a = 0; a < NT; ++a) {
                     const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(sw + a * 16 * 128 + co_lo), hi = *reinterpret_cast<const u32x4_t*>(sw + a * 16 * 128 + (co_lo ^ 64));
@@ -235,10 +245,23 @@ void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned c
                     wsc[a] = (int)(*reinterpret_cast<const unsigned*>(swb + WSTG + (wn * WN + a * 16 + l16) * 4) >> sh);
                 }
 #pragma unroll
-                for (int a = 0; a < NT; ++a)
+                for (int bh = 0; bh < MT; bh += 2) {
+                    i32x8_t xf[2];
+                    int xsc[2];
 #pragma unroll
-                    for (int b = 0; b < MT; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[a], xf[b], acc[a][b], 0, 0, 0, wsc[a], 0, xsc[b]);
+                    for (int b = 0; b < 2; ++b) {
+                        const unsigned a0 = rt_get(t, bh + b);
+                        const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(sx + a0), hi = *reinterpret_cast<const u32x4_t*>(sx + (a0 ^ 64u));
+                        xf[b] = i32x8_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+                        xsc[b] = (int)(*reinterpret_cast<const unsigned*>(sx + SBUF + ((a0 >> 7) << 2)) >> sh);
+                    }
+#pragma unroll
+                    for (int a = 0; a < NT; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            acc[a][bh + b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[a], xf[b], acc[a][bh + b], 0, 0, 0, wsc[a], 0, xsc[b]);
+                    if (bh == 0) __builtin_amdgcn_sched_barrier(0);      // keep the second half's loads behind the first half's MFMAs
+                }
                 // pin the accumulators here: the MFMAs are pure register operations, and without a use inside the step the
                 // optimiser sinks the whole chain of all nine taps below the last tap's loads (seen: 144 MFMAs after the last
                 // barrier, 550 registers of fragments spilled to scratch)
