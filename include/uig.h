@@ -178,6 +178,19 @@ int uig_instnorm_act_bwd_colsum_mx(const void* dy, const void* x, const float* s
  * scale = 2^(floor(log2(max|x|)) - 8) as an E8M0 byte (127 for an all-zero block), elements = RNE(x / scale) in e4m3,
  * saturated to +-448.  q: [P][C] bytes, scales: [P][C/32] bytes. */
 int uig_mx_quantize(const void* x, void* q, void* scales, long P, int C, int dtype, void* stream);
+/* the same for many bf16 matrices in one launch (all fp8 weight operands after the per-step repack): items_dev = device array of
+ * 40-byte records {const void* x; void* q; void* scales; int64 n8 = P*C/8; int64 block_end = inclusive prefix sum of ceil(n8/256)} */
+int uig_mx_quantize_multi(const void* items_dev, int nitems, long total_blocks, void* stream);
+/* Input gradient of a pad-1 REFLECTION 3x3 convolution on the MX fp8 kernel in ONE launch (the backward of reference
+ * networks.py:ResnetBlock's ReflectionPad2d(1)+Conv2d, models/networks.py:349-377): dq / ds = the MX-quantised output gradient
+ * [B,H,W,C], wq / ws (+ second network's wq2 / ws2 from image group_images on) = the MX-quantised tap-major weights of the transposed
+ * gather.  The mirrored lines / columns are "mirror pixels" built in LDS: sums of two (four at the corners) de-quantised pixels,
+ * re-quantised per 32-channel block with the rule of uig_mx_quantize.  res_add (nullable, [B,H,W,ldc] bf16): summed into dx in the
+ * epilogue.  Shapes: W == 64, H % 4 == 0, H >= 8, C and Nrows multiples of 128 (…_applicable returns 1). */
+int uig_conv3x3_mx_fp8_dgrad_mirror_applicable(int B, int H, int W, int Cin, int Nrows);
+int uig_conv3x3_mx_fp8_dgrad_mirror(const void* dq, const void* ds, const void* wq, const void* ws, const void* wq2, const void* ws2,
+                                    int group_images, const void* res_add, void* dx, int B, int H, int W, int Cin, int Nrows, int ldc,
+                                    void* stream);
 /* which strip kernel that launch runs on: 0 none (generic gather), 128 = 128x128 tiles, 256 = 256x128 tiles one per block,
  * 257 = 256x128 tiles on persistent blocks (tests assert the variant they mean to cover) */
 int uig_conv_strip_tile(int B, int H, int W, int Cin, int Nrows, int Ho, int Wo, int dh_min, int dh_max, int dtype);

@@ -63,6 +63,12 @@ store = _Store.apply
 wop = _OperandW.apply
 
 
+def mirror_dgrad_shape(shape) -> bool:
+    """the product's dispatch rule (uig_conv3x3_mx_fp8_dgrad_mirror_applicable): which fp8 layers take the one-launch input gradient"""
+    B, C, H, W = shape
+    return W == 64 and H >= 8 and H % 4 == 0 and C % 128 == 0
+
+
 class _MXConv3x3(torch.autograd.Function):
     """ReflectionPad2d(1) + Conv2d(k=3) of a ResBlock on the MX fp8 path.  x: bf16-representable activations, w fp32 master."""
 
@@ -75,14 +81,18 @@ class _MXConv3x3(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         wb = _bf(w)
-        # input gradient: fp8 main term (zero-padded transposed conv of the quantised dy) + the exact mirrored-border terms on bf16 operands
-        main = M.conv3x3_mx_dgrad_zero_pad(dy, w)
-        with torch.enable_grad():
-            xr = x.detach().requires_grad_(True)
-            full = F.conv2d(F.pad(xr, (1, 1, 1, 1), mode="reflect"), wb)
-            (gx_full,) = torch.autograd.grad(full, xr, dy)
-        zp = F.conv_transpose2d(dy, wb, None, 1, 1)
-        dx = main + (gx_full - zp)
+        if mirror_dgrad_shape(x.shape):
+            # 64-wide maps (the 256x256 configs): one launch, the mirrored terms as re-quantised mirror pixels (uig_conv3x3_mx_fp8_dgrad_mirror)
+            dx = M.conv3x3_mx_dgrad_reflect_mirror(dy, w)
+        else:
+            # input gradient: fp8 main term (zero-padded transposed conv of the quantised dy) + the exact mirrored-border terms on bf16 operands
+            main = M.conv3x3_mx_dgrad_zero_pad(dy, w)
+            with torch.enable_grad():
+                xr = x.detach().requires_grad_(True)
+                full = F.conv2d(F.pad(xr, (1, 1, 1, 1), mode="reflect"), wb)
+                (gx_full,) = torch.autograd.grad(full, xr, dy)
+            zp = F.conv_transpose2d(dy, wb, None, 1, 1)
+            dx = main + (gx_full - zp)
         # weight / bias gradients: bf16 operands (the un-quantised x and dy), fp32 result
         dw = torch.nn.grad.conv2d_weight(F.pad(x, (1, 1, 1, 1), mode="reflect"), w.shape, dy)
         return dx, dw, dy.sum((0, 2, 3))

@@ -65,3 +65,43 @@ def conv3x3_mx_dgrad_zero_pad(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor
     """input gradient of a ZERO-padded 3x3 stride-1 conv from MX-quantised dy and the dgrad weight operand (the main term of
     the reflection-pad gradient: the mirrored-border terms stay on the bf16 path)"""
     return F.conv_transpose2d(fake_quant_channels(dy), fake_quant_weight(w, 0), None, 1, 1)
+
+
+def conv3x3_mx_dgrad_reflect_mirror(dy: torch.Tensor, w: torch.Tensor, quant: bool = True) -> torch.Tensor:
+    """input gradient of a pad-1 REFLECTION 3x3 stride-1 conv as the one-launch fp8 kernel (uig_conv3x3_mx_fp8_dgrad_mirror) computes it:
+    a zero-padded transposed conv of the MX-quantised dy in which the taps that would touch a mirrored line / column read a "mirror
+    pixel" = the fp32 sum of two (four at the corners) de-quantised pixels, RE-QUANTISED per 32-channel block.  quant=False: no
+    quantisation anywhere - then the result must equal autograd's gradient of F.pad(reflect)+conv2d (the algebra check in tests/)."""
+    fq = fake_quant_channels if quant else (lambda t: t)
+    q = fq(dy.float())
+    wq = fake_quant_weight(w, 0) if quant else w.float()
+    B, C, H, W = q.shape
+
+    def sh(X, dh, dw):                       # Y[h][w] = X[h + dh][w + dw], zero outside
+        hh, ww = X.shape[2:]
+        P = F.pad(X, (1, 1, 1, 1))
+        return P[:, :, 1 + dh:1 + dh + hh, 1 + dw:1 + dw + ww]
+
+    px = lambda r, c: q[:, :, r:r + 1, c:c + 1]
+    mcl, mcr = fq(q[..., 2:3] + q[..., 0:1]), fq(q[..., W - 3:W - 2] + q[..., W - 1:W])            # column mirrors, one per row
+    mrt, mrb = fq(q[:, :, 2:3] + q[:, :, 0:1]), fq(q[:, :, H - 3:H - 2] + q[:, :, H - 1:H])        # line mirrors, one per column
+    corner = lambda ra, rb, ca, cb: fq(((px(ra, ca) + px(rb, ca)) + px(ra, cb)) + px(rb, cb))      # the device's summation order
+    dx = torch.zeros(B, w.shape[1], H, W)
+    for kh in range(3):
+        for kw in range(3):
+            dh, dw = 1 - kh, 1 - kw
+            S = sh(q, dh, dw).clone()
+            if dw == 1:
+                S[:, :, :, 1:2] = sh(mcl, dh, 0)
+            if dw == -1:
+                S[:, :, :, W - 2:W - 1] = sh(mcr, dh, 0)
+            if dh != 0:
+                row, m = (1, mrt) if dh == 1 else (H - 2, mrb)
+                ra, rb = (2, 0) if dh == 1 else (H - 3, H - 1)
+                S[:, :, row:row + 1, :] = sh(m, 0, dw)
+                if dw == 1:
+                    S[:, :, row:row + 1, 1:2] = corner(ra, rb, 2, 0)
+                if dw == -1:
+                    S[:, :, row:row + 1, W - 2:W - 1] = corner(ra, rb, W - 3, W - 1)
+            dx = dx + torch.einsum("bohw,oi->bihw", S, wq[:, :, kh, kw])
+    return dx

@@ -36,11 +36,16 @@ def test_mx_quantize_bytes_equal_emulation(dtype):
     assert torch.equal(q.cpu(), qr), f"{int((q.cpu() != qr).sum())} e4m3 bytes differ"
 
 
+@pytest.mark.parametrize("mirror", [True, False], ids=["dgrad-one-launch", "dgrad-border-gemm"])
 @pytest.mark.parametrize("B,group,S", [(32, 16, 64), (16, 8, 64), (8, 0, 64), (5, 2, 32)], ids=["paired32-config5", "paired16", "single8", "paired5-32px"])
-def test_conv3x3_mx_fp8_forward_and_dgrad_vs_emulation(B, group, S):
+def test_conv3x3_mx_fp8_forward_and_dgrad_vs_emulation(B, group, S, mirror, monkeypatch):
     """The ResBlock convolution (256->256 3x3 reflect) on the MX fp8 kernel: forward (+ fused InstanceNorm statistics) and the
-    input gradient (main term on fp8; mirrored-border terms on bf16; + the ResBlock skip gradient) against the emulation."""
+    input gradient (+ the ResBlock skip gradient) against the emulation, in both forms the product has: on 64-wide maps ONE launch with
+    re-quantised mirror pixels (the default; `mirror`), otherwise / with UIG_MX_DGRAD_MIRROR=0 the fp8 main term + the bf16 border GEMM."""
     u, ops, networks = _mods()
+    if S != 64 and not mirror:
+        pytest.skip("32-pixel maps take the border-GEMM form either way")
+    monkeypatch.setattr(ops, "MX_DGRAD_MIRROR", mirror)
     from oracle import mx_fp8 as M
     lib, dt = u.lib.lib(), torch.bfloat16
     torch.manual_seed(2000 + B)
@@ -84,13 +89,19 @@ def test_conv3x3_mx_fp8_forward_and_dgrad_vs_emulation(B, group, S):
     link.grad = ops.to_nhwc(res.cuda(), dt)
     yp.backward(ops.to_nhwc(dy.cuda(), dt))
     dx = ops.from_nhwc(xp.grad, 256).cpu()
-    main = torch.cat([M.conv3x3_mx_dgrad_zero_pad(bf(dy[a:e]), ws[i]) for a, e, i in parts])
-    # the exact reflection gradient minus the exact zero-pad gradient = the border terms (computed by the bf16 border GEMM)
     xr = bf(x).requires_grad_(True)
     full = torch.cat([F.conv2d(F.pad(xr[a:e], (1, 1, 1, 1), mode="reflect"), bf(ws[i])) for a, e, i in parts])
     full.backward(bf(dy))
-    zp = torch.cat([F.conv_transpose2d(bf(dy[a:e]), bf(ws[i]), None, 1, 1) for a, e, i in parts])
-    dxref = main + (xr.grad - zp) + bf(res)
+    one_launch = ops.MX_DGRAD_MIRROR and lib.uig_conv3x3_mx_fp8_dgrad_mirror_applicable(B, S, S, 256, 256) == 1
+    assert one_launch == (mirror and S == 64)
+    if one_launch:
+        # 64-wide maps: ONE launch, the mirrored lines / columns as re-quantised mirror pixels (uig_conv3x3_mx_fp8_dgrad_mirror)
+        dxref = torch.cat([M.conv3x3_mx_dgrad_reflect_mirror(bf(dy[a:e]), ws[i]) for a, e, i in parts]) + bf(res)
+    else:
+        main = torch.cat([M.conv3x3_mx_dgrad_zero_pad(bf(dy[a:e]), ws[i]) for a, e, i in parts])
+        # the exact reflection gradient minus the exact zero-pad gradient = the border terms (computed by the bf16 border GEMM)
+        zp = torch.cat([F.conv_transpose2d(bf(dy[a:e]), bf(ws[i]), None, 1, 1) for a, e, i in parts])
+        dxref = main + (xr.grad - zp) + bf(res)
     dxfull = xr.grad + bf(res)
     sc = float(dxfull.abs().max())
     d1, d2 = float((dx - dxref).abs().max()), float((dx - dxfull).abs().max())

@@ -72,3 +72,22 @@ def test_lowprec_steps_track_the_fp32_oracle():
         assert float((res[name][3] - res["f32"][3]).abs().max()) < (0.12 if name == "bf16" else 0.4)      # tanh output, 2-block generator on 16x16 maps
     # the stored outputs are bf16-representable
     assert torch.equal(res["bf16"][3], res["bf16"][3].to(torch.bfloat16).float())
+
+
+def test_mirror_pixel_dgrad_algebra_equals_reflect_pad_gradient():
+    """oracle/mx_fp8.conv3x3_mx_dgrad_reflect_mirror (the emulation of the one-launch fp8 input gradient) with quantisation switched
+    off must BE the gradient of ReflectionPad2d(1)+Conv2d: pins the mirror-pixel placement (which taps read which sums) on the CPU."""
+    import torch.nn.functional as F
+    from oracle import mx_fp8 as M
+    torch.manual_seed(11)
+    for H, W in ((8, 12), (5, 4), (16, 64)):
+        x = torch.randn(2, 32, H, W, requires_grad=True)
+        w = torch.randn(64, 32, 3, 3)
+        y = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w)
+        dy = torch.randn_like(y)
+        (g,) = torch.autograd.grad(y, x, dy)
+        d = M.conv3x3_mx_dgrad_reflect_mirror(dy, w, quant=False)
+        assert (d - g).abs().max() <= 1e-5 * g.abs().max()
+        # quantised: close to it (fp8 noise), and not the zero-pad gradient
+        dq = M.conv3x3_mx_dgrad_reflect_mirror(dy, w)
+        assert (dq - g).norm() <= 0.08 * g.norm()

@@ -29,7 +29,14 @@ struct MxDesc {
     unsigned xs_bytes, ws_bytes;
 };
 
-template <int CAP>
+// MIRROR (round 3): the input gradient of a REFLECTION-padded convolution in one launch, as in conv_strip_pk.hip - the taps that would
+// read a mirrored line / column read "mirror pixels" placed behind the tile's NS strip rows (same slot layout: NS + 8r + 2 / 5 column
+// mirrors, NS + 48 + c line mirror, + 66 / 69 its corners).  In fp8 a mirror pixel is the sum of two (four) pixels with DIFFERENT block
+// scales: each source chunk is de-quantised (e4m3 -> f32, times its block's E8M0 scale), the sum is taken in fp32 and re-quantised with
+// the MX rule (one new scale per 32 channels = two adjacent lanes' chunks: one xor-shuffle), data and scale byte written to the slot.
+// The scale dwords of the next chunk's strip are DMA'd in the chunk's FIRST step instead of its last, so that they have landed when
+// the mirror pixels are built at the top of the last step.  No border GEMM in front, no border loads in the epilogue.
+template <int CAP, bool MIRROR = false>
 __global__ __launch_bounds__(512, 2)
 void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned char* __restrict__ wp1, const float* __restrict__ bias1,
                            bf16_t* __restrict__ y, const MxDesc m) {
@@ -44,6 +51,7 @@ void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned c
     static_assert(NW * SCRW <= REG, "the epilogue scratch must fit the region the last K-step used");
     static_assert(CAP % 8 == 0 && PIECES <= NTAPS * NW && SPIECES <= NW, "one strip piece per wave per K-step");
     static_assert((CAP * 128) % SCRW + 1024 <= SCRW && SBUF + XSB <= (ZW + 1) * SCRW, "zero row and its scales inside one wave's scratch");
+    static_assert(!MIRROR || (6 * 64 + 48 <= CAP && 5 * 64 + 48 + 72 <= CAP), "mirror pixels: 64-wide maps");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
 
@@ -143,6 +151,83 @@ void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned c
         if (wave < 2) issue_ws(t.g2, ws_base(t, 0, 0), region);
     };
 
+    // ---- mirror pixels of one landed strip chunk (MIRROR): block-uniform control flow, no barrier inside.  Item = (mirror pixel,
+    //      16-byte chunk k = 16 channels); the two lanes k, k ^ 1 of a pixel hold one 32-channel scale block.
+    const int tpi_m = tpi;
+    auto mirror_fix = [&](int region, const Tile& t) {
+        if constexpr (MIRROR) {
+            unsigned char* sb = smem + region * REG;
+            unsigned char* xsb = sb + SBUF;
+            const int nrows = t.NS >> 6;
+            const bool top = t.ti == 0, edge = top || t.ti == tpi_m - 1;
+            const int rA = (top ? 2 : d.H - 3) - t.lo, rB = (top ? 0 : d.H - 1) - t.lo;
+            const int nitem = (edge ? 12 + 66 : 12) * 8;
+            auto ld = [&](int slot, int k, float (&f)[16]) {
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(sb + slot * 128 + (((k + (slot & 6)) & 7) << 4));
+                const unsigned sc = (*reinterpret_cast<const unsigned*>(xsb + slot * 4) >> (8 * (k >> 1))) & 0xffu;
+                const float scale = __uint_as_float(sc << 23);                         // 2^(sc - 127)
+#pragma unroll
+                for (int dw_ = 0; dw_ < 4; ++dw_) {
+                    const auto lo2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[dw_], false), hi2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[dw_], true);
+                    f[4 * dw_] = lo2[0] * scale; f[4 * dw_ + 1] = lo2[1] * scale; f[4 * dw_ + 2] = hi2[0] * scale; f[4 * dw_ + 3] = hi2[1] * scale;
+                }
+            };
+            for (int i = tid; i < nitem; i += 64 * NW) {
+                const int px = i >> 3, k = i & 7;
+                int s0, s1, s2 = -1, s3 = -1;
+                bool live = true;
+                if (px < 12) {
+                    const int side = px >= 6 ? 1 : 0, r = px - 6 * side;
+                    live = r < nrows;                                                  // the same for both lanes of a scale block
+                    s0 = r * 64 + (side ? d.W - 3 : 2); s1 = r * 64 + (side ? d.W - 1 : 0);
+                } else {
+                    const int c = px - 12;
+                    if (c < 64) { s0 = rA * 64 + c; s1 = rB * 64 + c; }
+                    else {
+                        const int ca = c == 64 ? 2 : d.W - 3, cb = c == 64 ? 0 : d.W - 1;
+                        s0 = rA * 64 + ca; s1 = rB * 64 + ca; s2 = rA * 64 + cb; s3 = rB * 64 + cb;
+                    }
+                }
+                if (!live) { s0 = s1 = 0; }
+                float f[16], g[16];
+                ld(s0, k, f); ld(s1, k, g);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) f[e] += g[e];
+                if (s2 >= 0) {
+                    ld(s2, k, g);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) f[e] += g[e];
+                    ld(s3, k, g);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) f[e] += g[e];
+                }
+                // MX re-quantisation of the 32-channel block held by lanes k (even) and k ^ 1: the rule of mx_quantize8
+                float am = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) am = fmaxf(am, fabsf(f[e]));
+                am = fmaxf(am, __shfl_xor(am, 1, 64));
+                const int eb = (int)((__float_as_uint(am) >> 23) & 0xff);
+                const int sbn = am == 0.f ? 127 : min(max(eb - 8, 0), 254);
+                const float inv = __uint_as_float((unsigned)(254 - sbn) << 23);
+                u32x4_t o;
+#pragma unroll
+                for (int dw_ = 0; dw_ < 4; ++dw_) {
+                    float v4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v4[e] = fminf(fmaxf(f[4 * dw_ + e] * inv, -448.f), 448.f);
+                    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v4[0], v4[1], 0, false);
+                    pk = __builtin_amdgcn_cvt_pk_fp8_f32(v4[2], v4[3], pk, true);
+                    o[dw_] = (unsigned)pk;
+                }
+                if (live) {
+                    const int so = t.NS + (px < 12 ? 8 * (px % 6) + (px >= 6 ? 5 : 2) : 48 + (px - 12 < 64 ? px - 12 : (px - 12 == 64 ? 66 : 69)));
+                    *reinterpret_cast<u32x4_t*>(sb + so * 128 + (((k + (so & 6)) & 7) << 4)) = o;
+                    if ((k & 1) == 0) xsb[so * 4 + (k >> 1)] = (unsigned char)sbn;
+                }
+            }
+        }
+    };
+
     Tile cur = get_tile(0);
     if (!cur.valid) return;
     __syncthreads();
@@ -181,7 +266,16 @@ void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned c
             }
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) {
-                const int s0 = hrow[t / 3] + wcol[t % 3];
+                int s0 = hrow[t / 3] + wcol[t % 3];
+                if constexpr (MIRROR) {                 // taps that read a mirror pixel instead (only where the plain tap is inside the image)
+                    const int dh_ = (d.tap[3 * (t / 3)] & 255) - 128, dw_ = ((d.tap[t % 3] >> 8) & 255) - 128;
+                    const bool ra = (ho == 1 && dh_ == 1) || (ho == d.H - 2 && dh_ == -1);
+                    const bool cl = wo == 1 && dw_ == 1, cr = wo == d.W - 2 && dw_ == -1;
+                    if (s0 >= 0) {
+                        if (ra) s0 = tl.NS + 48 + (cl ? 66 : (cr ? 69 : wo + dw_));
+                        else if (cl | cr) s0 = tl.NS + 8 * (ho + dh_ - tl.lo) + (cr ? 5 : 2);
+                    }
+                }
                 const int s = (pv & (s0 >= 0)) ? s0 : CAP;
                 const unsigned av = (unsigned)(s * 128 + (((q + (s & 6)) & 7) << 4)) & 0xffffu;
                 const int ri = t * MT + b;
@@ -199,6 +293,13 @@ void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned c
     for (int r = 0;; ++r) {
         const Tile nxt = get_tile(r + 1);
         if (cur.ti != rt_ti) { build_rt(cur); rt_ti = cur.ti; }
+        if constexpr (MIRROR) {
+            if (r == 0) {                                      // the block's first chunk: nothing ran in front of it to hide this behind
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                mirror_fix(0, cur);
+            }
+        }
         const float* bias = cur.g2 ? d.bias2 : bias1;
 
         f32x4_t acc[NT][MT];
@@ -229,7 +330,10 @@ void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned c
                 }
                 const int slot = t * NW + wave;
                 if (s_on && slot < PIECES && 8 * slot < s_NS) issue_strip_piece(slot, s_base, s_NS, pc ^ 1);
-                if (t == NTAPS - 1 && s_on && wave < SPIECES && 64 * wave < s_NS) issue_xs_piece(wave, x_base, s_NS, pc ^ 1);
+                if (t == (MIRROR ? 0 : NTAPS - 1) && s_on && wave < SPIECES && 64 * wave < s_NS) issue_xs_piece(wave, x_base, s_NS, pc ^ 1);
+                if constexpr (MIRROR) {      // next chunk's strip (steps 0-6) and scales (step 0) have landed and been published: its mirror pixels
+                    if (last_t && s_on) mirror_fix(pc ^ 1, last_cc ? nxt : cur);
+                }
 
                 const unsigned char* swb = smem + (pc ^ (t & 1)) * REG + SBUF + XSB;
                 const unsigned char* sw = swb + (wn * WN + l16) * 128;
@@ -278,7 +382,7 @@ void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned c
         unsigned char* scratch = smem + pl * REG + wave * SCRW;
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
-        strip_epilogue<bf16_t, MT, NT, WM, WN>(acc, scratch, d, y, cur.img, cur.p0, wm, wn, cur.n_base, lane_e);
+        strip_epilogue<bf16_t, MT, NT, WM, WN, !MIRROR>(acc, scratch, d, y, cur.img, cur.p0, wm, wn, cur.n_base, lane_e);
         if (!nxt.valid) break;
         if (wave == ZW) {                                      // restore the zero row and its scales (the scratch covered them)
             *reinterpret_cast<u32x4_t*>(smem + pl * REG + CAP * 128 + lane * 16) = u32x4_t{0u, 0u, 0u, 0u};
@@ -289,7 +393,8 @@ void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned c
     }
 }
 
-template __global__ void conv_strip_fp8_kernel<448>(const unsigned char*, const unsigned char*, const float*, bf16_t*, const MxDesc);
+template __global__ void conv_strip_fp8_kernel<448, false>(const unsigned char*, const unsigned char*, const float*, bf16_t*, const MxDesc);
+template __global__ void conv_strip_fp8_kernel<448, true>(const unsigned char*, const unsigned char*, const float*, bf16_t*, const MxDesc);
 
 static int fp8_device_cus() {
     static const int n = [] {
@@ -308,6 +413,24 @@ static int strip_rows_needed256(int H, int W, int dh_min, int dh_max) {
         worst = std::max(worst, (hi - lo + 1) * W);
     }
     return worst;
+}
+
+template <bool MIRROR>
+static int launch_mx(const MxDesc& m, const void* xq, const void* wq, const float* bias, void* y, void* stream) {
+    constexpr int CAP = 448;
+    const StripDesc& d = m.d;
+    const size_t smem = 2 * ((size_t)(CAP + 8) * 128 + (CAP + 8) * 4 + 128 * 128 + 128 * 4);
+    auto kern = conv_strip_fp8_kernel<CAP, MIRROR>;
+    static SmemAttrOnce attr_once;
+    {
+        hipError_t e = attr_once.ensure(reinterpret_cast<const void*>(kern), smem);
+        if (e != hipSuccess) return uig_set_error((int)e, "conv_strip_fp8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    }
+    const int ntiles = d.B * ((d.H * d.W + 255) / 256) * (d.Nrows / 128);
+    hipLaunchKernelGGL(kern, dim3(std::min(ntiles, fp8_device_cus())), dim3(512), smem, (hipStream_t)stream,
+                       (const unsigned char*)xq, (const unsigned char*)wq, bias, (bf16_t*)y, m);
+    UIG_LAUNCH_CHECK("uig_conv3x3_mx_fp8");
+    return 0;
 }
 
 extern "C" int uig_conv3x3_mx_fp8_applicable(int B, int H, int W, int Cin, int Nrows) {
@@ -348,19 +471,37 @@ extern "C" int uig_conv3x3_mx_fp8(const void* xq, const void* xs, const void* wq
     if (bst_partial != nullptr) { d.bst_x = bst_x; d.bst_stats = bst_stats; d.bst_partial = bst_partial; d.bst_act = bst_act; d.bst_slope = bst_slope; }
     m.xs = (const unsigned char*)xs; m.ws = (const unsigned char*)ws; m.ws2 = (const unsigned char*)ws2;
     m.xs_bytes = (unsigned)((long)B * H * W * (Cin / 32)); m.ws_bytes = (unsigned)((long)Nrows * 9 * (Cin / 32));
-    constexpr int CAP = 448;
-    const size_t smem = 2 * ((size_t)(CAP + 8) * 128 + (CAP + 8) * 4 + 128 * 128 + 128 * 4);
-    auto kern = conv_strip_fp8_kernel<CAP>;
-    static SmemAttrOnce attr_once;
-    {
-        hipError_t e = attr_once.ensure(reinterpret_cast<const void*>(kern), smem);
-        if (e != hipSuccess) return uig_set_error((int)e, "conv_strip_fp8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    }
-    const int ntiles = B * ((H * W + 255) / 256) * (Nrows / 128);
-    hipLaunchKernelGGL(kern, dim3(std::min(ntiles, fp8_device_cus())), dim3(512), smem, (hipStream_t)stream,
-                       (const unsigned char*)xq, (const unsigned char*)wq, bias, (bf16_t*)y, m);
-    UIG_LAUNCH_CHECK("uig_conv3x3_mx_fp8");
-    return 0;
+    return launch_mx<false>(m, xq, wq, bias, y, stream);
+}
+
+// The input gradient of a REFLECTION-padded 3x3 convolution, fp8 operands, in one launch (MIRROR variant of the kernel above): dq / ds
+// = MX-quantised output gradient [B,H,W,C], wq / ws = the MX-quantised tap-major weights of the transposed gather.  Replaces
+// uig_conv3x3_mx_fp8(pad zero, transposed) + the bf16 border GEMM (uig_conv_dgrad_border) of the round-2 form.
+extern "C" int uig_conv3x3_mx_fp8_dgrad_mirror_applicable(int B, int H, int W, int Cin, int Nrows) {
+    if (uig_conv3x3_mx_fp8_applicable(B, H, W, Cin, Nrows) != 1) return 0;
+    return (W == 64 && H >= 8 && H % 4 == 0) ? 1 : 0;
+}
+
+extern "C" int uig_conv3x3_mx_fp8_dgrad_mirror(const void* dq, const void* ds, const void* wq, const void* ws, const void* wq2, const void* ws2,
+                                               int group_images, const void* res_add, void* dx, int B, int H, int W, int Cin, int Nrows, int ldc,
+                                               void* stream) {
+    UIG_CHECK_ARG(dq && ds && wq && ws && dx, "uig_conv3x3_mx_fp8_dgrad_mirror: null pointer");
+    UIG_CHECK_ARG(uig_conv3x3_mx_fp8_dgrad_mirror_applicable(B, H, W, Cin, Nrows) == 1,
+                  "uig_conv3x3_mx_fp8_dgrad_mirror: unsupported shape B=%d %dx%d Cin=%d N=%d (64-wide maps, H %% 4 == 0, channels multiples of 128)", B, H, W, Cin, Nrows);
+    UIG_CHECK_ARG(ldc >= Nrows && (ldc * 2) % 16 == 0, "uig_conv3x3_mx_fp8_dgrad_mirror: bad ldc %d", ldc);
+    if (wq2 != nullptr) UIG_CHECK_ARG(ws2 != nullptr && group_images > 0 && group_images < B, "uig_conv3x3_mx_fp8_dgrad_mirror: bad pair (group_images=%d, B=%d)", group_images, B);
+    MxDesc m{};
+    StripDesc& d = m.d;
+    d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Ho = H; d.Wo = W; d.pad_mode = UIG_PAD_ZERO; d.dh_min = -1; d.dh_max = 1;
+    d.Nrows = Nrows; d.ldw = 9 * Cin; d.ldc = ldc; d.Nstore = Nrows; d.act = UIG_ACT_NONE; d.slope = 0.f;
+    d.x_bytes = (unsigned)((long)B * H * W * Cin); d.w_bytes = (unsigned)((long)Nrows * 9 * Cin);
+    d.wp2 = wq2; d.group_images = group_images; d.res_add = res_add;
+    for (int kh = 0; kh < 3; ++kh)
+        for (int kw = 0; kw < 3; ++kw) d.tap[kh * 3 + kw] = ((1 - kh) + 128) | (((1 - kw) + 128) << 8) | ((kh * 3 + kw) << 16);
+    d.wo_magic = ((1 << 20) + W - 1) / W;
+    m.xs = (const unsigned char*)ds; m.ws = (const unsigned char*)ws; m.ws2 = (const unsigned char*)ws2;
+    m.xs_bytes = (unsigned)((long)B * H * W * (Cin / 32)); m.ws_bytes = (unsigned)((long)Nrows * 9 * (Cin / 32));
+    return launch_mx<true>(m, dq, wq, nullptr, dx, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -388,6 +529,43 @@ __global__ void mx_quantize_kernel(const T* __restrict__ x, unsigned char* __res
         *reinterpret_cast<u32x2_t*>(q + 8 * i) = w;
         if ((i & 3) == 0) s[i >> 2] = (unsigned char)sb;
     }
+}
+
+// Every fp8 weight operand of every layer in ONE launch (the per-step refresh after Adam + repack: 72 quantiser launches of ~4 us
+// each at the launch floor otherwise).  items: device array of {x (bf16), q, s, n8 (16-byte chunks of 8 elements), block_end}
+// records (40 bytes), block_end = inclusive prefix sum of ceil(n8 / 256): a block of 256 threads finds its record by bisection.
+struct MxQItem { const bf16_t* x; unsigned char* q; unsigned char* s; long n8; long block_end; };
+__global__ __launch_bounds__(256) void mx_quantize_multi_kernel(const MxQItem* __restrict__ items, int nitems) {
+    __shared__ int s_item;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = nitems - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (items[mid].block_end > (long)blockIdx.x) hi = mid; else lo = mid + 1; }
+        s_item = lo;
+    }
+    __syncthreads();
+    const int ii = s_item;
+    const MxQItem it = items[ii];
+    const long b0 = ii ? items[ii - 1].block_end : 0;
+    const long i = ((long)blockIdx.x - b0) * 256 + threadIdx.x;
+    const bool ok = i < it.n8;
+    float f[8];
+    if (ok) chunk_to_f32<bf16_t>(*reinterpret_cast<const u32x4_t*>(it.x + 8 * i), f);
+    else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = 0.f;
+    }
+    int sb;
+    const u32x2_t w = mx_quantize8(f, sb);
+    if (ok) {
+        *reinterpret_cast<u32x2_t*>(it.q + 8 * i) = w;
+        if ((i & 3) == 0) it.s[i >> 2] = (unsigned char)sb;
+    }
+}
+extern "C" int uig_mx_quantize_multi(const void* items_dev, int nitems, long total_blocks, void* stream) {
+    UIG_CHECK_ARG(items_dev && nitems > 0 && total_blocks > 0 && total_blocks < (1L << 31), "uig_mx_quantize_multi: bad args");
+    hipLaunchKernelGGL(mx_quantize_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const MxQItem*)items_dev, nitems);
+    UIG_LAUNCH_CHECK("uig_mx_quantize_multi");
+    return 0;
 }
 
 extern "C" int uig_mx_quantize(const void* x, void* q, void* scales, long P, int C, int dtype, void* stream) {

@@ -49,6 +49,9 @@ SIGNATURES = {
     "uig_conv3x3_mx_fp8_applicable": (_i, [_i] * 5),
     "uig_conv3x3_mx_fp8": (_i, [_vp] * 8 + [_i] + [_vp] * 4 + [_i] * 8 + [_i, _f] + [_vp, _vp, _i, _f, _vp] + [_vp]),
     "uig_mx_quantize": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "uig_mx_quantize_multi": (_i, [_vp, _i, _i64, _vp]),
+    "uig_conv3x3_mx_fp8_dgrad_mirror_applicable": (_i, [_i] * 5),
+    "uig_conv3x3_mx_fp8_dgrad_mirror": (_i, [_vp] * 6 + [_i, _vp, _vp] + [_i] * 6 + [_vp]),
     "uig_instnorm_act_fwd_mx": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _f, _i, _f, _i, _vp]),
     "uig_instnorm_act_bwd_colsum_pre": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _i, _f, _i, _vp]),
     "uig_instnorm_act_bwd_colsum_mx": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _vp]),

@@ -30,6 +30,7 @@ PARALLEL_BACKWARD = os.environ.get("UIG_PARALLEL_BACKWARD", "0") != "0"
 # 16.08-16.33 ms with it vs 15.98-16.00 ms without (same box).  ~700 VALU instructions per wave at 2 waves per SIMD sit on the
 # convolution's critical path, while the stand-alone pass is HBM-bound at full occupancy.  Tested opt-in (test_ops_gpu.py).
 FUSE_BWD_STATS = os.environ.get("UIG_FUSE_BWD_STATS", "0") != "0"
+MX_DGRAD_MIRROR = os.environ.get("UIG_MX_DGRAD_MIRROR", "1") != "0"   # fp8 layers: reflect-pad input gradient in one launch (mirror pixels re-quantised in LDS) instead of fp8 main term + bf16 border GEMM
 FUSE_MX_QUANT = os.environ.get("UIG_FUSE_MX_QUANT", "1") != "0"            # fp8 path: MX quantisation of activations / gradients inside the InstanceNorm launches
 # ResBlock: conv2 applies the InstanceNorm + ReLU in front of it to its own input strip (NormConvFn): no apply pass between the block's two convolutions
 NORM_CONV = os.environ.get("UIG_NORM_CONV", "0") != "0"      # OFF by default: measured slower (13.64 vs 13.48 ms per step; g_fwd 2.45 vs 2.34 ms) - see DESIGN.md
@@ -307,17 +308,33 @@ class MultiPacker:
         self.dtype = self.layers[0].compute_dtype
         self.items = torch.from_numpy(arr.view(np.uint8).copy()).to(self.layers[0].weight.device)
         self.n = len(recs)
+        # fp8 layers: the MX quantisation of both packed operands of every such layer as ONE more launch (uig_mx_quantize_multi)
+        qdt = np.dtype([("x", "<u8"), ("q", "<u8"), ("s", "<u8"), ("n8", "<i8"), ("block_end", "<i8")])
+        qrecs, qend = [], 0
+        self.qptrs = []
+        for l in self.layers:
+            if l.fp8:
+                for wp, wq, ws in ((l.wp_fwd, l.wq_fwd, l.ws_fwd), (l.wp_dgrad, l.wq_dgrad, l.ws_dgrad)):
+                    n8 = wp.numel() // 8
+                    qend += (n8 + 255) // 256
+                    qrecs.append((wp.data_ptr(), wq.data_ptr(), ws.data_ptr(), n8, qend))
+                    self.qptrs.append((wq, ws))
+        self.qn, self.qblocks = len(qrecs), qend
+        self.qitems = torch.from_numpy(np.array(qrecs, dtype=qdt).view(np.uint8).copy()).to(self.layers[0].weight.device) if qrecs else None
 
     def valid(self):
-        return all(p == (l.weight.data_ptr(), l.wp_fwd.data_ptr(), l.wp_dgrad.data_ptr()) for p, l in zip(self.ptrs, self.layers))
+        return all(p == (l.weight.data_ptr(), l.wp_fwd.data_ptr(), l.wp_dgrad.data_ptr()) for p, l in zip(self.ptrs, self.layers)) and \
+            self.qn == 2 * sum(1 for l in self.layers if l.fp8) and \
+            all(a is b and c is d for (a, c), (b, d) in zip(self.qptrs, [(w, s_) for l in self.layers if l.fp8
+                                                                         for w, s_ in ((l.wq_fwd, l.ws_fwd), (l.wq_dgrad, l.ws_dgrad))]))
 
     def run(self):
         dt = L.BF16 if self.dtype == torch.bfloat16 else L.F32
         L.check(L.lib().uig_pack_weights_multi(_p(self.items), self.n, self.total, dt, _stream()), "uig_pack_weights_multi")
+        if self.qitems is not None:
+            L.check(L.lib().uig_mx_quantize_multi(_p(self.qitems), self.qn, self.qblocks, _stream()), "uig_mx_quantize_multi")
         for l in self.layers:
             l._packed_version = l.weight._version
-            if l.fp8:
-                l.quantize_packed()
 
 
 def packed_shapes(spec: ConvSpec):
@@ -455,8 +472,12 @@ def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, 
     mirror = (spec.kind == "conv" and spec.reflect and spec.k == 3 and spec.pad == 1 and spec.stride == 1 and REFLECT_DGRAD_DIRECT
               and mx is None and spec.cin_p == spec.cin and not (bst is not None and FUSE_BWD_STATS)
               and L.lib().uig_reflect3x3_dgrad_mirror_applicable(B, Ho, Wo, Cd, spec.cin, spec.cin_p, _dt(dy)) == 1)
+    # the same on the MX fp8 kernel (round 3): mirror pixels re-quantised in LDS, no bf16 border GEMM in front
+    mx_mirror = (mx is not None and MX_DGRAD_MIRROR and spec.kind == "conv" and spec.reflect and spec.k == 3 and spec.pad == 1 and spec.stride == 1
+                 and REFLECT_DGRAD_DIRECT and spec.cin_p == spec.cin and not (bst is not None and FUSE_BWD_STATS) and dy.dtype == torch.bfloat16
+                 and L.lib().uig_conv3x3_mx_fp8_dgrad_mirror_applicable(B, Ho, Wo, Cd, spec.cin) == 1)
     if res_add is not None:
-        fusable = (spec.kind == "conv" and spec.reflect and spec.k == 3 and spec.pad == 1 and spec.stride == 1 and ((H == W and 4 <= H <= 128) or mirror)
+        fusable = (spec.kind == "conv" and spec.reflect and spec.k == 3 and spec.pad == 1 and spec.stride == 1 and ((H == W and 4 <= H <= 128) or mirror or mx_mirror)
                    and REFLECT_DGRAD_DIRECT and FUSE_SKIP_GRAD and res_add.is_contiguous() and res_add.dtype == dy.dtype
                    and tuple(res_add.shape) == (B, H, W, spec.cin_p)
                    and L.lib().uig_conv_strip_applicable(B, Ho, Wo, Cd, spec.cin, H, W, -1, 1, _dt(dy)) == 1)
@@ -467,6 +488,13 @@ def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, 
         dx = torch.empty((B, H, W, spec.cin_p), device=dy.device, dtype=dy.dtype)
         _gather(dy, wp_dgrad, None, dx, B, Ho, Wo, Cd, spec.cin, spec, spec.stride, spec.pad, L.PAD_ZERO, L.GATHER_DIRECT, H, W,
                 spec.cin_p, L.ACT_NONE, 0.0, "uig_conv_gather(convT dgrad)", pair)
+        return dx
+    if mx_mirror:
+        wq2, ws2 = (mx[2], mx[3]) if len(mx) == 4 else (None, None)
+        dx = torch.empty((B, H, W, spec.cin_p), device=dy.device, dtype=dy.dtype)
+        dq, ds = _mx_operand(dy)
+        L.check(L.lib().uig_conv3x3_mx_fp8_dgrad_mirror(_p(dq), _p(ds), _p(mx[0]), _p(mx[1]), _p(wq2), _p(ws2), pair[2] if pair is not None else 0,
+                                                        _p(res_add), _p(dx), B, Ho, Wo, Cd, spec.cin, spec.cin_p, s), "uig_conv3x3_mx_fp8_dgrad_mirror")
         return dx
     if mirror or (spec.reflect and spec.k == 3 and spec.pad == 1 and spec.stride == 1 and H == W and 4 <= H <= 128 and REFLECT_DGRAD_DIRECT
                   and L.lib().uig_conv_strip_applicable(B, Ho, Wo, Cd, spec.cin, H, W, -1, 1, _dt(dy)) == 1):
