@@ -17,7 +17,8 @@ def t(fn, n=40):
     e0.record()
     for _ in range(n): fn()
     e1.record(); e1.synchronize(); return e0.elapsed_time(e1) * 1e3 / n
-VARIANTS = {"tile/block": (3, 0, 0), "pk": (1, 0, 0), "pk no-xprefetch": (1, 12, 0), "pk nolgk": (1, 4, 0), "pk rd0-dma": (1, 8, 0), "pk rdall-dma": (1, 9, 0), "pk setprio": (1, 10, 0)}
+VARIANTS = {"tile/block": (3, 0, 0), "pk": (1, 0, 0), "pk no-xprefetch": (1, 12, 0), "pk nolgk": (1, 4, 0), "pk rd0-dma": (1, 8, 0), "pk rdall-dma": (1, 9, 0), "pk setprio": (1, 10, 0),
+            "pk 4iss": (1, 20, 0), "pk pkrt": (1, 21, 0)}      # round 3: four issuing waves + packed row table; packed row table alone
 if os.environ.get("PK_VARIANTS"):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k == "tile/block" or k in os.environ["PK_VARIANTS"].split(",")}
 lib.uig_debug_set_mirror(0)      # the input gradient in its border-buffer form on every variant, so that dx is comparable bitwise
@@ -49,3 +50,22 @@ for (v, B), xs in sorted(res.items(), key=lambda kv: (kv[0][1], kv[0][0])):
     fl = 2.0 * B * 4096 * 256 * 2304 / 1e6
     print(f"  B{B:2d} {v:12s} fwd {fs[len(fs)//2]:6.1f} ({fl/fs[len(fs)//2]:5.0f} TF = {fl/fs[len(fs)//2]/2500:.3f} of peak)   dgrad {gs[len(gs)//2]:6.1f} ({fl/gs[len(gs)//2]:5.0f} TF)")
 lib.uig_debug_set_strip(1); lib.uig_debug_set_strip_pk(0, 0); lib.uig_debug_set_mirror(1)
+
+# round 3: the mirror-pixel input gradient (the step's form) on the issuing-wave variants, bitwise against the default persistent kernel
+lib.uig_debug_set_mirror(1)
+mres, mref = {}, {}
+for rnd in range(3):
+    for v in [k for k in ("pk", "pk 4iss", "pk pkrt") if k in VARIANTS]:
+        select(v)
+        for B in (16, 8):
+            x = (torch.rand(B, 64, 64, 256, device="cuda", generator=torch.Generator("cuda").manual_seed(B)) * 2 - 1).to(dt)
+            r = (torch.rand(B, 64, 64, 256, device="cuda", generator=torch.Generator("cuda").manual_seed(B + 1)) * 2 - 1).to(dt)
+            g = lambda: ops.conv_dgrad(l1.spec, x, l1.wp_dgrad, (64, 64), pair=(l2.wp_dgrad, None, B // 2), res_add=r)
+            dx = g()
+            if v == "pk" and B not in mref: mref[B] = dx.clone()
+            assert torch.equal(dx, mref[B]), f"mirror-pixel dgrad of {v} differs from the default persistent kernel"
+            mres.setdefault((v, B), []).append(t(g))
+select("pk")
+print("mirror-pixel dgrad + res, medians (us):")
+for (v, B), xs in sorted(mres.items(), key=lambda kv: (kv[0][1], kv[0][0])):
+    print(f"  B{B:2d} {v:12s} {sorted(xs)[len(xs)//2]:6.1f}")

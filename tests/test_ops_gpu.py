@@ -1050,3 +1050,42 @@ def test_strip_persistent_512_row_strip_on_128_wide_maps(B, group):
     zn = ops.from_nhwc(networks.InstNormAct(u.lib.ACT_RELU)(yp), C).cpu()            # consumes the statistics partials of this launch
     zref = F.relu(F.instance_norm(y, eps=1e-5))
     assert (zn - zref).abs().max() <= _tol(dt, zref)
+
+
+@pytest.mark.parametrize("S,cin,cout,B,group", [(64, 256, 256, 1, 0), (64, 256, 256, 3, 1), (16, 64, 128, 2, 0), (32, 128, 256, 5, 2), (24, 192, 128, 1, 0)],
+                         ids=["b1-64px-infer", "b3-paired", "one-chunk", "two-chunks-paired", "three-chunks"])
+def test_strip128_deep_weight_prefetch_equals_two_stage_kernel(S, cin, cout, B, group):
+    """Round 3: the 128x128-tile bf16 strip kernel with FOUR weight stages (tiles fetched three K-steps ahead, counted vmcnt: the
+    batch-1 inference path, grids <= 256 blocks) must be bit-identical to the two-stage kernel (same accumulation order), forward
+    with the fused InstanceNorm statistics and reflect-pad input gradient, and both close to the stock-torch convolution on
+    bf16-rounded operands.  Cin = 64 / 128 / 192 / 256: 9, 18, 27, 36 K-steps (the counted wait's tail cases)."""
+    u, ops, networks = _mods()
+    import torch.nn.functional as F
+    lib, dt = u.lib.lib(), torch.bfloat16
+    torch.manual_seed(31 + S + B)
+    ls = [networks.ConvLayer("conv", cin, cout, 3, 1, 1, "reflect", dtype=dt, device="cuda") for _ in range(2 if group else 1)]
+    for l in ls:
+        l.repack()
+    assert lib.uig_conv_strip_tile(B, S, S, cin, cout, S, S, -1, 1, u.lib.BF16) == 128
+    x = ((torch.rand(B, S, S, cin, device="cuda") * 2 - 1)).to(dt)
+    dy = (torch.randn(B, S, S, cout, device="cuda") * 0.5).to(dt)
+    fpair = (ls[1].wp_fwd, ls[1].bias, group) if group else None
+    bpair = (ls[1].wp_dgrad, None, group) if group else None
+    outs = {}
+    try:
+        for n in (2, 4):
+            lib.uig_debug_set_strip_stages(n)
+            y = ops.conv_forward(ls[0].spec, x, ls[0].wp_fwd, ls[0].bias, pair=fpair, want_in_stats=True)
+            dx = ops.conv_dgrad(ls[0].spec, dy, ls[0].wp_dgrad, (S, S), bpair)
+            torch.cuda.synchronize()
+            outs[n] = (y.clone(), y._uig_in_partial[0].clone(), dx.clone())
+    finally:
+        lib.uig_debug_set_strip_stages(0)
+    for a, b, name in zip(outs[2], outs[4], ("y", "InstanceNorm partial statistics", "dx")):
+        assert torch.equal(a, b), f"{name}: four-stage kernel differs from the two-stage kernel"
+    g = group if group else B
+    xr = ops.from_nhwc(x, cin).float().cpu()
+    ref = torch.cat([F.conv2d(F.pad(xr[a:e], (1, 1, 1, 1), mode="reflect"), l.weight.detach().to(dt).float().cpu(), l.bias.detach().float().cpu())
+                     for (a, e), l in zip(((0, g), (g, B)), ls) if e > a])
+    got = ops.from_nhwc(outs[4][0], cout).float().cpu()
+    assert (got - ref).abs().max() <= 1.6e-2 * ref.abs().max()

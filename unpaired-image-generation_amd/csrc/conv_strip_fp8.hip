@@ -36,7 +36,9 @@ struct MxDesc {
 // the MX rule (one new scale per 32 channels = two adjacent lanes' chunks: one xor-shuffle), data and scale byte written to the slot.
 // The scale dwords of the next chunk's strip are DMA'd in the chunk's FIRST step instead of its last, so that they have landed when
 // the mirror pixels are built at the top of the last step.  No border GEMM in front, no border loads in the epilogue.
-template <int CAP, bool MIRROR = false>
+// STAMP: diagnostic build (scripts/stamp_fp8.py): per wave, s_memtime sums {total, step wait + barrier, DMA issue (+ mirror pixels), fragment
+// reads + MFMAs, epilogue, row table, tiles} to d.dbg.
+template <int CAP, bool MIRROR = false, bool STAMP = false, int NISS = 4>
 __global__ __launch_bounds__(512, 2)
 void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned char* __restrict__ wp1, const float* __restrict__ bias1,
                            bf16_t* __restrict__ y, const MxDesc m) {
@@ -120,9 +122,15 @@ void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned c
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsxs, (__attribute__((address_space(3))) void*)dst, 4, (int)off, (int)sbase, 0, 0);
     };
     // ---- weight tile DMA: rows n_base + lr + 64 i (XOR swizzle: rows are 16-aligned per MFMA tile), and its scale dwords
-    unsigned wvl[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) wvl[i] = (unsigned)((lr + 64 * i) * d.ldw + (ch ^ ((lr >> 1) & 7)) * 16);
+    // NISS (round 3): only waves 0 .. NISS-1 issue the K loop's DMAs (16 / NISS weight pieces, NW / NISS strip pieces per step each).  A
+    // 1-KiB LDS-DMA instruction occupies the CU's one address path for ~16 cycles and a wave sits in its issue until the path takes it: with
+    // all eight waves issuing their 3-4 pieces behind the step's barrier, every wave stood there ~450 cycles per step (in-kernel stamps)
+    // with the matrix pipes empty.  Now the non-issuing wave of every SIMD goes straight to its fragment reads and MFMAs (-3 .. -6 % per
+    // launch, A/B in one process; placing the pieces one by one behind the step's first MFMAs instead measured the same with 8 issuing
+    // waves and worse with 4, and running the two waves of a SIMD half a step apart - two barriers per step - measured 4 % slower).
+    static_assert(NISS == 4 || NISS == 8, "issuing waves");
+    constexpr int WPI = 16 / NISS;                                                 // weight pieces per issuing wave and step
+    const unsigned wvl0 = (unsigned)(lr * d.ldw + (ch ^ ((lr >> 1) & 7)) * 16);   // piece wave + NISS i: rows + 8 NISS i (same swizzle term)
     auto w_base = [&](const Tile& t, int tp, int cc) -> unsigned {
         const int te = __builtin_amdgcn_readfirstlane(d.tap[tp]);
         return (unsigned)__builtin_amdgcn_readfirstlane(t.n_base * d.ldw + (te >> 16) * Cin + cc * BK);
@@ -132,9 +140,10 @@ void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned c
         return (unsigned)__builtin_amdgcn_readfirstlane((t.n_base * NTAPS + (te >> 16)) * CB + cc * 4);
     };
     auto issue_w1 = [&](int i, bool g2, unsigned so, int region) {
-        lds_ptr_t dst = (lds_ptr_t)smem + region * REG + SBUF + XSB + wave * 1024 + i * 64 * 128;
-        if (g2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw2, (__attribute__((address_space(3))) void*)dst, 16, (int)wvl[i], (int)so, 0, 0);
-        else    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw1, (__attribute__((address_space(3))) void*)dst, 16, (int)wvl[i], (int)so, 0, 0);
+        lds_ptr_t dst = (lds_ptr_t)smem + region * REG + SBUF + XSB + (wave + NISS * i) * 1024;
+        const int soi = (int)so + i * NISS * 8 * d.ldw;
+        if (g2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw2, (__attribute__((address_space(3))) void*)dst, 16, (int)wvl0, soi, 0, 0);
+        else    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw1, (__attribute__((address_space(3))) void*)dst, 16, (int)wvl0, soi, 0, 0);
     };
     auto issue_ws = [&](bool g2, unsigned so, int region) {     // waves 0 and 1: the scale dwords of weight rows 64 wave + lane
         lds_ptr_t dst = (lds_ptr_t)smem + region * REG + SBUF + XSB + WSTG + wave * 256;
@@ -147,7 +156,10 @@ void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned c
         for (int j = wave; 8 * j < t.NS; j += NW) issue_strip_piece(j, sb, t.NS, region);
         if (wave < SPIECES && 64 * wave < t.NS) issue_xs_piece(wave, xb, t.NS, region);
         const unsigned so = w_base(t, 0, 0);
-        issue_w1(0, t.g2, so, region); issue_w1(1, t.g2, so, region);
+        if (wave < NISS) {
+#pragma unroll
+            for (int i = 0; i < WPI; ++i) issue_w1(i, t.g2, so, region);
+        }
         if (wave < 2) issue_ws(t.g2, ws_base(t, 0, 0), region);
     };
 
@@ -228,6 +240,17 @@ void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned c
         }
     };
 
+    auto now = [&]() -> unsigned long long {
+        if constexpr (STAMP) {
+            unsigned long long tt;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            return tt;
+        } else return 0ull;
+    };
+    unsigned long long st_wait = 0, st_issue = 0, st_mma = 0, st_epi = 0, st_rt = 0, st_tiles = 0;
+    const unsigned long long st_t0 = now();
     Tile cur = get_tile(0);
     if (!cur.valid) return;
     __syncthreads();
@@ -292,7 +315,9 @@ void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned c
     int par = 0;
     for (int r = 0;; ++r) {
         const Tile nxt = get_tile(r + 1);
+        const unsigned long long st_a = now();
         if (cur.ti != rt_ti) { build_rt(cur); rt_ti = cur.ti; }
+        if constexpr (STAMP) { st_rt += now() - st_a; ++st_tiles; }
         if constexpr (MIRROR) {
             if (r == 0) {                                      // the block's first chunk: nothing ran in front of it to hide this behind
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -305,36 +330,60 @@ void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned c
         f32x4_t acc[NT][MT];
         strip_init_acc<MT, NT, WN>(acc, bias, d.Nrows, cur.n_base, wn, lane);
 
+        // the DMA issue that belongs to step (cc, t): the NEXT step's weights + their scales, one piece of the next chunk's strip, its scales
+        // (plain scalars, no Tile references selected at run time: those put the two Tile objects into scratch memory)
+        const unsigned sb_c = strip_base(cur, 0), sb_n = strip_base(nxt, 0), xb_c = xs_base(cur, 0), xb_n = xs_base(nxt, 0);
+        const int NS_c = cur.NS, NS_n = nxt.NS, nb_c = cur.n_base, nb_n = nxt.n_base;
+        const bool g2_c = cur.g2, g2_n = nxt.g2, nxt_ok = nxt.valid;
+        constexpr int NK = WPI + 1 + NW / NISS;
+        auto issue_piece = [&](int cc, int t, int k) {
+            const int pc = par ^ (cc & 1);
+            const bool last_cc = cc + 1 == ncc, last_t = t + 1 == NTAPS;
+            const bool pre_next = last_cc && nxt_ok;
+            const bool s_on = !last_cc || pre_next;
+            const unsigned s_base = !last_cc ? sb_c + (unsigned)((cc + 1) * BK) : sb_n;
+            const unsigned x_base = !last_cc ? xb_c + (unsigned)((cc + 1) * 4) : xb_n;
+            const int s_NS = !last_cc ? NS_c : NS_n;
+            const bool w_on = !(last_t && last_cc) || pre_next;
+            const bool wrap = last_t && last_cc;                               // the next step is the next tile's first
+            const bool w_g2 = wrap ? g2_n : g2_c;
+            const int tn = last_t ? 0 : t + 1, ccn = wrap ? 0 : (last_t ? cc + 1 : cc), nbn = wrap ? nb_n : nb_c;
+            const int te = __builtin_amdgcn_readfirstlane(d.tap[tn]) >> 16;
+            const unsigned w_so = (unsigned)__builtin_amdgcn_readfirstlane(nbn * d.ldw + te * Cin + ccn * BK);
+            const unsigned ws_so = (unsigned)__builtin_amdgcn_readfirstlane((nbn * NTAPS + te) * CB + ccn * 4);
+            const int w_reg = pc ^ ((t + 1) & 1);
+            // piece k of the step's NK DMA instructions of this wave: WPI weight pieces, the weight scales (waves 0, 1), NW / NISS strip pieces + scales
+            if (k < WPI) { if (w_on) issue_w1(k, w_g2, w_so, w_reg); }
+            else if (k == WPI) { if (w_on && wave < 2) issue_ws(w_g2, ws_so, w_reg); }
+            else {
+                const int kk = k - WPI - 1;
+                const int slot = t * NW + wave + NISS * kk;
+                if (s_on && slot < PIECES && 8 * slot < s_NS) issue_strip_piece(slot, s_base, s_NS, pc ^ 1);
+                const int xp = wave + NISS * kk;
+                if (t == (MIRROR ? 0 : NTAPS - 1) && s_on && xp < SPIECES && 64 * xp < s_NS) issue_xs_piece(xp, x_base, s_NS, pc ^ 1);
+            }
+        };
         for (int cc = 0; cc < ncc; ++cc) {
             const int pc = par ^ (cc & 1);
             const unsigned char* sx = smem + pc * REG;
             const bool last_cc = cc + 1 == ncc;
-            const bool pre_next = last_cc && nxt.valid;
-            const bool s_on = !last_cc || pre_next;
-            const unsigned s_base = !last_cc ? strip_base(cur, cc + 1) : strip_base(nxt, 0);
-            const unsigned x_base = !last_cc ? xs_base(cur, cc + 1) : xs_base(nxt, 0);
-            const int s_NS = !last_cc ? cur.NS : nxt.NS;
+            const bool s_on = !last_cc || nxt_ok;
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) {
+                const unsigned long long st_0 = now();
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
+                const unsigned long long st_1 = now();
                 const bool last_t = t + 1 == NTAPS;
-                const bool w_on = !(last_t && last_cc) || pre_next;
-                const bool w_g2 = (last_t && last_cc) ? nxt.g2 : cur.g2;
-                const unsigned w_so = !last_t ? w_base(cur, t + 1, cc) : (!last_cc ? w_base(cur, 0, cc + 1) : w_base(nxt, 0, 0));
-                const unsigned ws_so = !last_t ? ws_base(cur, t + 1, cc) : (!last_cc ? ws_base(cur, 0, cc + 1) : ws_base(nxt, 0, 0));
-                const int w_reg = pc ^ ((t + 1) & 1);
-                if (w_on) {
-                    issue_w1(0, w_g2, w_so, w_reg); issue_w1(1, w_g2, w_so, w_reg);
-                    if (wave < 2) issue_ws(w_g2, ws_so, w_reg);
+                if (wave < NISS) {
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) issue_piece(cc, t, k);
                 }
-                const int slot = t * NW + wave;
-                if (s_on && slot < PIECES && 8 * slot < s_NS) issue_strip_piece(slot, s_base, s_NS, pc ^ 1);
-                if (t == (MIRROR ? 0 : NTAPS - 1) && s_on && wave < SPIECES && 64 * wave < s_NS) issue_xs_piece(wave, x_base, s_NS, pc ^ 1);
                 if constexpr (MIRROR) {      // next chunk's strip (steps 0-6) and scales (step 0) have landed and been published: its mirror pixels
                     if (last_t && s_on) mirror_fix(pc ^ 1, last_cc ? nxt : cur);
                 }
 
+                const unsigned long long st_2 = now();
                 const unsigned char* swb = smem + (pc ^ (t & 1)) * REG + SBUF + XSB;
                 const unsigned char* sw = swb + (wn * WN + l16) * 128;
                 // Round 3: the step's fragments in two halves over the pixel groups (4 weight fragments + 2 x 2 strip fragments: 48 operand
@@ -373,9 +422,11 @@ void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned c
                 for (int a = 0; a < NT; ++a)
 #pragma unroll
                     for (int b = 0; b < MT; ++b) asm volatile("" : "+v"(acc[a][b]));
+                if constexpr (STAMP) { const unsigned long long st_3 = now(); st_wait += st_1 - st_0; st_issue += st_2 - st_1; st_mma += st_3 - st_2; }
             }
         }
         const int pl = par ^ ((ncc - 1) & 1);
+        const unsigned long long st_e = now();
 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -383,6 +434,7 @@ void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned c
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         strip_epilogue<bf16_t, MT, NT, WM, WN, !MIRROR>(acc, scratch, d, y, cur.img, cur.p0, wm, wn, cur.n_base, lane_e);
+        if constexpr (STAMP) st_epi += now() - st_e;
         if (!nxt.valid) break;
         if (wave == ZW) {                                      // restore the zero row and its scales (the scratch covered them)
             *reinterpret_cast<u32x4_t*>(smem + pl * REG + CAP * 128 + lane * 16) = u32x4_t{0u, 0u, 0u, 0u};
@@ -391,10 +443,16 @@ void conv_strip_fp8_kernel(const unsigned char* __restrict__ x, const unsigned c
         par = pl ^ 1;
         cur = nxt;
     }
+    if constexpr (STAMP) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st_end = now();
+        if (lane == 0 && d.dbg != nullptr) {
+            unsigned long long* o = d.dbg + ((long)blockIdx.x * NW + wave) * 8;
+            o[0] = st_end - st_t0; o[1] = st_wait; o[2] = st_issue; o[3] = st_mma; o[4] = st_epi; o[5] = st_rt; o[6] = st_tiles; o[7] = 0;
+        }
+    }
 }
 
-template __global__ void conv_strip_fp8_kernel<448, false>(const unsigned char*, const unsigned char*, const float*, bf16_t*, const MxDesc);
-template __global__ void conv_strip_fp8_kernel<448, true>(const unsigned char*, const unsigned char*, const float*, bf16_t*, const MxDesc);
 
 static int fp8_device_cus() {
     static const int n = [] {
@@ -415,12 +473,24 @@ static int strip_rows_needed256(int H, int W, int dh_min, int dh_max) {
     return worst;
 }
 
-template <bool MIRROR>
-static int launch_mx(const MxDesc& m, const void* xq, const void* wq, const float* bias, void* y, void* stream) {
+static unsigned long long* g_mx_dbg = nullptr;      // diagnostic: device buffer for the STAMP build (8 x u64 per wave)
+extern "C" void uig_debug_set_mx_stamps(void* dev_buf) { g_mx_dbg = (unsigned long long*)dev_buf; }
+
+static int g_mx_niss = 4;    // tuning / A-B hook: waves that issue the K loop's DMAs (8 = all: the round-2 form)
+extern "C" void uig_debug_set_mx_issuers(int n) { g_mx_niss = n == 8 ? 8 : 4; }
+
+template <bool MIRROR, bool STAMP = false, int NISS = 4>
+static int launch_mx(const MxDesc& m_in, const void* xq, const void* wq, const float* bias, void* y, void* stream) {
     constexpr int CAP = 448;
+    if constexpr (!STAMP && NISS == 4) {
+        if (g_mx_dbg != nullptr) return g_mx_niss == 8 ? launch_mx<MIRROR, true, 8>(m_in, xq, wq, bias, y, stream) : launch_mx<MIRROR, true, 4>(m_in, xq, wq, bias, y, stream);
+        if (g_mx_niss == 8) return launch_mx<MIRROR, false, 8>(m_in, xq, wq, bias, y, stream);
+    }
+    MxDesc m = m_in;
+    if constexpr (STAMP) m.d.dbg = g_mx_dbg;
     const StripDesc& d = m.d;
     const size_t smem = 2 * ((size_t)(CAP + 8) * 128 + (CAP + 8) * 4 + 128 * 128 + 128 * 4);
-    auto kern = conv_strip_fp8_kernel<CAP, MIRROR>;
+    auto kern = conv_strip_fp8_kernel<CAP, MIRROR, STAMP, NISS>;
     static SmemAttrOnce attr_once;
     {
         hipError_t e = attr_once.ensure(reinterpret_cast<const void*>(kern), smem);

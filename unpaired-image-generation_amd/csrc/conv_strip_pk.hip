@@ -58,7 +58,7 @@
 // NOZ (round 3): no zero rows behind the strip - for launches that never read one (reflection padding, whole tiles): the strip may then
 // be CAP = 512 rows (2 x 80 KB of LDS exactly, 16-bit row table up to 65,520), i.e. a 256-pixel tile of a 128-pixel-wide map (two
 // image rows + two halo rows): the ResBlock forward convolutions of the 512x512 configuration on this kernel instead of the generic one.
-template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false, bool MIRROR = false, bool NORM = false, bool NOZ = false>
+template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false, bool MIRROR = false, bool NORM = false, bool NOZ = false, int NISS = 8, bool PKRT = false>
 __global__ __launch_bounds__(512, 2)
 void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, const float* __restrict__ bias1, T* __restrict__ y,
                           const StripDesc d) {
@@ -134,23 +134,35 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
     };
     // ---- weight tile DMA: rows n_base + lr + 64 i, 16-byte chunk ch of physical slot ch ^ ((row >> 1) & 7) (rows are 16-aligned
     //      per MFMA tile, the XOR form is conflict-free there)
-    unsigned wvl[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) wvl[i] = (unsigned)(((lr + 64 * i) * d.ldw + (ch ^ ((lr >> 1) & 7)) * E) * (int)sizeof(T));
+    // NISS (round 3): only waves 0 .. NISS-1 issue the K loop's DMAs (16 / NISS weight pieces + NW / NISS strip pieces per step each).  A
+    // 1-KiB LDS-DMA instruction occupies the CU's one address path for ~16-20 cycles and a wave sits in its issue until the path takes it:
+    // with all eight waves issuing their three pieces behind the step's barrier, every wave stood there for the whole burst with the matrix
+    // pipes empty (in-kernel stamps of the fp8 kernel: ~450 cycles per step).  With NISS = 4 the other wave of every SIMD goes straight to
+    // its fragment reads and MFMAs.  NORM keeps 8: its waves normalise the strip pieces they issued themselves.  Measured on this kernel
+    // (scripts/bench_strip_pk.py, variants 20 / 21): forward 69.6 -> 67.9 us, mirror-pixel input gradient 75.3 -> 77.4 us - the packed row
+    // table the variant needs to stay clear of spills costs about what the issuing split gains, so 8 stays the default here (the fp8
+    // kernel, whose row table was packed already, takes 4).
+    static_assert((NISS == 4 || NISS == 8) && (!NORM || NISS == 8), "issuing waves");
+    constexpr int WPI = 16 / NISS;                             // weight pieces per issuing wave and step: piece wave + NISS i = rows + 8 NISS i (same swizzle term)
+    const unsigned wvl0 = (unsigned)((lr * d.ldw + (ch ^ ((lr >> 1) & 7)) * E) * (int)sizeof(T));
     auto w_base = [&](const Tile& t, int tp, int cc) -> unsigned {
         const int te = __builtin_amdgcn_readfirstlane(d.tap[tp]);
         return (unsigned)__builtin_amdgcn_readfirstlane((t.n_base * d.ldw + (te >> 16) * Cin + cc * BK) * (int)sizeof(T));
     };
     auto issue_w1 = [&](int i, bool g2, unsigned so, int region) {
-        lds_ptr_t dst = (lds_ptr_t)smem + region * REG + SBUF + wave * 1024 + i * 64 * 128;
-        if (g2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw2, (__attribute__((address_space(3))) void*)dst, 16, (int)wvl[i], (int)so, 0, 0);
-        else    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw1, (__attribute__((address_space(3))) void*)dst, 16, (int)wvl[i], (int)so, 0, 0);
+        lds_ptr_t dst = (lds_ptr_t)smem + region * REG + SBUF + (wave + NISS * i) * 1024;
+        const int soi = (int)so + i * NISS * 8 * d.ldw * (int)sizeof(T);
+        if (g2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw2, (__attribute__((address_space(3))) void*)dst, 16, (int)wvl0, soi, 0, 0);
+        else    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw1, (__attribute__((address_space(3))) void*)dst, 16, (int)wvl0, soi, 0, 0);
     };
     auto issue_first = [&](const Tile& t, int region) {       // a tile's chunk-0 strip and first weight tile, all at once
         const unsigned sb = strip_base(t, 0);
         for (int j = wave; 8 * j < t.NS; j += NW) issue_strip_piece(j, sb, t.NS, region);
         const unsigned so = w_base(t, 0, 0);
-        issue_w1(0, t.g2, so, region); issue_w1(1, t.g2, so, region);
+        if (wave < NISS) {
+#pragma unroll
+            for (int i = 0; i < WPI; ++i) issue_w1(i, t.g2, so, region);
+        }
     };
 
     // ---- mirror pixels of one strip chunk (MIRROR): see the kernel comment.  Block-uniform control flow, no barrier inside.
@@ -260,7 +272,27 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
     // ---- per-lane row table: LDS byte address (within a strip buffer, K half 0) of the B-operand row of output pixel
     //      (tile row wm*64 + b*16 + l16) displaced by tap t; half 1 of the 128-byte row is address ^ 64.
     //      Taps form a 3x3 grid: dh depends on t / 3 only, dw on t % 3 only (checked on the host).
-    unsigned short rt[NTAPS][MT];
+    // PKRT: two 16-bit entries per register, unpacked at the point of use behind a compiler barrier (18 registers instead of 36: what the
+    // four-issuing-wave variants need to stay clear of spills)
+    unsigned rtw[PKRT ? NTAPS * MT / 2 : NTAPS * MT];
+    auto rt_get = [&](int t, int b) -> unsigned {
+        const int i = t * MT + b;
+        if constexpr (PKRT) {
+            unsigned v = rtw[i >> 1];
+            asm volatile("" : "+v"(v));
+            return (i & 1) ? (v >> 16) : (v & 0xffffu);
+        } else return rtw[i];
+    };
+    auto rt_set = [&](int t, int b, unsigned av) {
+        const int i = t * MT + b;
+        av &= 0xffffu;
+        if constexpr (PKRT) rtw[i >> 1] = (i & 1) ? ((rtw[i >> 1] & 0xffffu) | (av << 16)) : ((rtw[i >> 1] & 0xffff0000u) | av);
+        else rtw[i] = av;
+    };
+    if constexpr (PKRT) {
+#pragma unroll
+        for (int i = 0; i < NTAPS * MT / 2; ++i) rtw[i] = 0u;
+    }
     int rt_ti = -1;
     // Every lane builds its own table (8 waves x 2 per SIMD on the VALU: ~8 cycles per instruction at the head of the launch), so
     // the address is kept SEPARABLE: W is a multiple of 16 (host-checked), hence the swizzle term of slot hv + wv depends on wv
@@ -314,7 +346,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                 int a;
                 if constexpr (MIRROR) a = ra[i] ? TA[j] : (ca[j] ? CA[i] : A[i]) + Bj[j];
                 else a = A[i] + Bj[j];
-                rt[t][b] = (unsigned short)((NOZ || (hok[i] & wok[j])) ? a : Z[j]);      // NOZ: host-checked that no tap leaves the image
+                rt_set(t, b, (unsigned)((NOZ || (hok[i] & wok[j])) ? a : Z[j]));      // NOZ: host-checked that no tap leaves the image
             }
         }
     };
@@ -365,11 +397,24 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                 const bool w_g2 = (last_t && last_cc) ? nxt.g2 : cur.g2;
                 const unsigned w_so = !last_t ? w_base(cur, t + 1, cc) : (!last_cc ? w_base(cur, 0, cc + 1) : w_base(nxt, 0, 0));
                 const int w_reg = pc ^ ((t + 1) & 1);
-                const int slot = t * NW + wave;
-                const bool p_on = s_on && slot < PIECES && 8 * slot < s_NS;
-                auto dma = [&](int which) {                     // 0 / 1: the two halves of the next weight tile, 2: this wave's strip piece
-                    if (which < 2) { if (w_on) issue_w1(which, w_g2, w_so, w_reg); }
-                    else if (p_on) issue_strip_piece(slot, s_base, s_NS, pc ^ 1);
+                constexpr int NK = WPI + NW / NISS;             // DMA instructions of an issuing wave per step
+                auto dma_piece = [&](int k) {                   // k < WPI: weight piece k of the next step; else strip piece k - WPI of the next chunk
+                    if (k < WPI) { if (w_on) issue_w1(k, w_g2, w_so, w_reg); }
+                    else {
+                        const int slot = t * NW + wave + NISS * (k - WPI);
+                        if (s_on && slot < PIECES && 8 * slot < s_NS) issue_strip_piece(slot, s_base, s_NS, pc ^ 1);
+                    }
+                };
+                auto dma = [&](int which) {                     // 0 / 1: the two halves of the next weight tile, 2: this wave's strip pieces
+                    if (wave < NISS) {
+                        if (which < 2) {
+#pragma unroll
+                            for (int i = 0; i < WPI / 2; ++i) dma_piece(which * (WPI / 2) + i);
+                        } else {
+#pragma unroll
+                            for (int k = WPI; k < NK; ++k) dma_piece(k);
+                        }
+                    }
                 };
                 if constexpr (DM == 0 || DM == 4 || DM == 5) { dma(0); dma(1); dma(2); }
                 if constexpr (MIRROR) {
@@ -396,7 +441,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                             for (int b = 0; b < MT; ++b) xf[b] = xn[b];
                         } else {
 #pragma unroll
-                            for (int b = 0; b < MT; ++b) xf[b] = *reinterpret_cast<const u32x4_t*>(sx + ((unsigned)rt[t][b] ^ (unsigned)(h << 6)));
+                            for (int b = 0; b < MT; ++b) xf[b] = *reinterpret_cast<const u32x4_t*>(sx + (rt_get(t, b) ^ (unsigned)(h << 6)));
                         }
 #pragma unroll
                         for (int a = 0; a < NT; ++a)
@@ -414,19 +459,19 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                     }
                     if (!last_t) {
 #pragma unroll
-                        for (int b = 0; b < MT; ++b) xn[b] = *reinterpret_cast<const u32x4_t*>(sx + (unsigned)rt[(t + 1) % NTAPS][b]);
+                        for (int b = 0; b < MT; ++b) xn[b] = *reinterpret_cast<const u32x4_t*>(sx + rt_get((t + 1) % NTAPS, b));
                     } else if (!MIRROR && !NORM && !last_cc) { // the next chunk's strip is complete since step 7's barrier (mirror / norm kernel: its
                                                                // mirror pixels are only published by the NEXT barrier - fresh reads there)
                         const unsigned char* sxn = smem + (pc ^ 1) * REG;
 #pragma unroll
-                        for (int b = 0; b < MT; ++b) xn[b] = *reinterpret_cast<const u32x4_t*>(sxn + (unsigned)rt[0][b]);
+                        for (int b = 0; b < MT; ++b) xn[b] = *reinterpret_cast<const u32x4_t*>(sxn + rt_get(0, b));
                     }
                 } else if constexpr (DM == 3) {                 // all 16 fragment reads of the step first, then the DMAs, then 32 MFMAs
                     u32x4_t xf[2][MT], wf[2][NT];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                        for (int b = 0; b < MT; ++b) xf[h][b] = *reinterpret_cast<const u32x4_t*>(sx + ((unsigned)rt[t][b] ^ (unsigned)(h << 6)));
+                        for (int b = 0; b < MT; ++b) xf[h][b] = *reinterpret_cast<const u32x4_t*>(sx + (rt_get(t, b) ^ (unsigned)(h << 6)));
                         const int co = ((q + 4 * h) ^ wswz) << 4;
 #pragma unroll
                         for (int a = 0; a < NT; ++a) wf[h][a] = *reinterpret_cast<const u32x4_t*>(sw + a * 16 * 128 + co);
@@ -445,7 +490,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
                 for (int h = 0; h < 2; ++h) {
                     u32x4_t xf[MT], wf[NT];
 #pragma unroll
-                    for (int b = 0; b < MT; ++b) xf[b] = *reinterpret_cast<const u32x4_t*>(sx + ((unsigned)rt[t][b] ^ (unsigned)(h << 6)));
+                    for (int b = 0; b < MT; ++b) xf[b] = *reinterpret_cast<const u32x4_t*>(sx + (rt_get(t, b) ^ (unsigned)(h << 6)));
                     const int co = ((q + 4 * h) ^ wswz) << 4;
 #pragma unroll
                     for (int a = 0; a < NT; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(sw + a * 16 * 128 + co);
@@ -523,10 +568,10 @@ static int device_cus() {
     return n;
 }
 
-template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false, bool MIRROR = false, bool NORM = false, bool NOZ = false>
+template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false, bool MIRROR = false, bool NORM = false, bool NOZ = false, int NISS = 8, bool PKRT = false>
 static int launch_pk(const void* x, const void* wp, const float* bias, void* y, const StripDesc& d, int ntiles, hipStream_t s) {
     const size_t smem = 2 * ((size_t)(CAP + (NOZ ? 0 : 8)) * 128 + 128 * 128) + (NORM ? (size_t)4 * 256 * 8 : 0);      // NORM: (mean, rstd) of 4 images x <= 256 channels
-    auto kern = conv_strip_pk_kernel<T, CAP, DM, SWZ, LGK, STAMP, MIRROR, NORM, NOZ>;
+    auto kern = conv_strip_pk_kernel<T, CAP, DM, SWZ, LGK, STAMP, MIRROR, NORM, NOZ, NISS, PKRT>;
     static SmemAttrOnce attr_once;
     {
         hipError_t e = attr_once.ensure(reinterpret_cast<const void*>(kern), smem);
@@ -561,11 +606,19 @@ int uig_launch_strip_pk(const void* x, const void* wp, const float* bias, void* 
         return launch_pk<bf16_t, 448, 5, 1, true, false, false, true>(x, wp, bias, y, d, ntiles, s);
     }
     if (dtype == UIG_BF16) {
-        if (d.mirror) return d.dbg != nullptr ? launch_pk<bf16_t, 448, 0, 1, true, true, true>(x, wp, bias, y, d, ntiles, s)
-                                              : (g_pk_dm == 12 ? launch_pk<bf16_t, 448, 0, 1, true, false, true>(x, wp, bias, y, d, ntiles, s)
-                                                               : launch_pk<bf16_t, 448, 5, 1, true, false, true>(x, wp, bias, y, d, ntiles, s));
+        if (d.mirror) {
+            if (d.dbg != nullptr) return launch_pk<bf16_t, 448, 0, 1, true, true, true>(x, wp, bias, y, d, ntiles, s);
+            switch (g_pk_dm) {
+                case 12: return launch_pk<bf16_t, 448, 0, 1, true, false, true>(x, wp, bias, y, d, ntiles, s);
+                case 20: return launch_pk<bf16_t, 448, 5, 1, true, false, true, false, false, 4, true>(x, wp, bias, y, d, ntiles, s);
+                case 21: return launch_pk<bf16_t, 448, 5, 1, true, false, true, false, false, 8, true>(x, wp, bias, y, d, ntiles, s);
+                default: return launch_pk<bf16_t, 448, 5, 1, true, false, true>(x, wp, bias, y, d, ntiles, s);
+            }
+        }
         if (d.dbg != nullptr) return launch_pk<bf16_t, 448, 0, 1, true, true>(x, wp, bias, y, d, ntiles, s);
         switch (g_pk_dm) {      // tuning variants (A/B in one process: scripts/bench_strip_pk.py)
+            case 20: return launch_pk<bf16_t, 448, 5, 1, true, false, false, false, false, 4, true>(x, wp, bias, y, d, ntiles, s);   // four issuing waves, packed row table
+            case 21: return launch_pk<bf16_t, 448, 5, 1, true, false, false, false, false, 8, true>(x, wp, bias, y, d, ntiles, s);   // eight issuing waves, packed row table
             case 2: return launch_pk<bf16_t, 448, 0, 0, true>(x, wp, bias, y, d, ntiles, s);      // XOR swizzle (for the bank-conflict counters)
             case 4: return launch_pk<bf16_t, 448, 0, 1, false>(x, wp, bias, y, d, ntiles, s);     // no lgkmcnt wait before the barrier
             case 8: return launch_pk<bf16_t, 448, 2, 1, false>(x, wp, bias, y, d, ntiles, s);     // reads of half 0, then the DMAs

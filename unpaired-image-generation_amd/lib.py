@@ -30,7 +30,10 @@ SIGNATURES = {
     "uig_debug_set_mirror": (None, [_i]),
     "uig_debug_set_strip_pk": (None, [_i, _i]),
     "uig_debug_set_rowstrip": (None, [_i]),
+    "uig_debug_set_strip_stages": (None, [_i]),
     "uig_debug_set_strip_stamps": (None, [_vp]),
+    "uig_debug_set_mx_stamps": (None, [_vp]),
+    "uig_debug_set_mx_issuers": (None, [_i]),
     "uig_conv2d_fwd_workspace_bytes": (_sz, [_i] * 10),
     "uig_conv2d_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 11 + [_vp, _sz, _vp]),
     "uig_conv_gather": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_i, _f, _i, _vp]),
