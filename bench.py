@@ -26,6 +26,36 @@ PEAK_F32 = 157.3e12
 PEAK_FP8 = 5.0e15     # dense MX-scaled fp8 MFMA peak
 
 
+def exchange_bandwidth(torch, dist, model, dev, world, iters=10):
+    """time the all-reduces one step issues (same bucket slices of the flat gradient buffers, same process group) without the compute"""
+    bufs, saved = [], []
+    for grad, buckets in ((model.grp_G.grad, model.buckets_G), (model.grp_D.grad, model.buckets_D)):
+        saved.append((grad, grad.clone()))
+        bufs += [(grad, a, b) for a, b in buckets]
+    nbytes = sum((b - a) * 4 for _, a, b in bufs)
+    st = torch.cuda.Stream(device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    with torch.cuda.stream(st):
+        for it in range(iters + 2):
+            if it == 2:
+                e0.record(st)
+            for grad, a, b in bufs:
+                dist.all_reduce(grad[a:b], op=dist.ReduceOp.SUM)
+        e1.record(st)
+    e1.synchronize()
+    for grad, keep in saved:
+        grad.copy_(keep)                                       # the sums of the timing loop are not gradients
+    ms = e0.elapsed_time(e1) / iters
+    t = torch.tensor([ms], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms = float(t.item())
+    alg = nbytes / (ms * 1e-3) / 1e9
+    return {"what": "the step's gradient all-reduces (bucketed slices of the flat fp32 G and D gradient buffers) alone, back to back, max over ranks",
+            "buckets": len(bufs), "bytes_per_step": nbytes, "allreduce_ms": round(ms, 4), "alg_bw_GBps": round(alg, 2),
+            "bus_bw_GBps": round(alg * 2 * (world - 1) / world, 2), "world": world}
+
+
 def step_flops(size, n_blocks=9):
     s = (size / 256.0) ** 2
     return (18 * F_G256 + 16 * F_D256) * s if n_blocks == 9 else None
@@ -134,6 +164,10 @@ def main():
         "step_mfma_peak": {"f32": "157.3 TF f32 MFMA", "bf16": "2.5 PF dense bf16", "fp8": "FLOP-weighted: ResBlock conv fwd+dgrad at 5 PF MX-fp8, the rest at 2.5 PF bf16"}[args.dtype],
         "losses": {k: round(v, 4) for k, v in losses.items()},
     }
+    if world > 1 or args.force_comm:
+        # the step's gradient exchange alone (every rank takes part): the buckets the staged backward all-reduces, back to back on one
+        # stream, HIP-event timed; bus bandwidth = 2 (N - 1) / N x bytes / time; at N = 1 (plumbing run) the factor is 0
+        out["comm"] = exchange_bandwidth(torch, dist, model, dev, world)
     if rank == 0:
         out["roofline"] = dominant_kernel_roofline(u, torch, dev, dtype, 4 * B, S // 4, args.kernel_iters, fp8=args.dtype == "fp8")
         if args.dtype == "bf16" and S % 4 == 0:

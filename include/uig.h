@@ -58,8 +58,8 @@ void uig_debug_set_strip_pk(int dm, int grid);
 void uig_debug_set_mirror(int on);
 /* tuning / test hook: 1 (default) = 7x7 stride-1 convs with <= 16 output channels use the row-strip kernel */
 void uig_debug_set_rowstrip(int on);
+void uig_debug_set_strip_stages(int n);           /* 128x128-tile bf16 strip kernel: weight stages 2 (default) / 4 (three K-steps ahead, counted waits: measured slower, A-B hook) */
 /* diagnostic build hook: device buffer (u64[blocks*8*4]) that receives in-kernel cycle stamps; NULL = off (default) */
-void uig_debug_set_strip_stages(int n);           /* 128x128-tile bf16 strip kernel: weight stages 2 / 4, 0 = auto (4 on grids of <= 256 blocks) */
 void uig_debug_set_strip_stamps(void* dev_buf);
 void uig_debug_set_mx_issuers(int n);            /* MX fp8 kernel A-B hook: waves of a block that issue the K loop's DMAs (4 default, 8 = all: the round-2 form) */
 void uig_debug_set_mx_stamps(void* dev_buf);      /* the same for the MX fp8 kernel: 8 x u64 per wave {total, wait, issue, reads+MFMA, epilogue, row table, tiles, 0} */

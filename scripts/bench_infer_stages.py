@@ -1,5 +1,5 @@
 """Generator-only inference latency (Translator, one HIP graph per shape): the 128x128-tile strip kernel with two weight stages against
-four (tiles fetched three K-steps ahead, the default on grids of <= 256 blocks), alternated in one process; plus a serialised
+four (tiles fetched three K-steps ahead; opt-in, measured slower), alternated in one process; plus a serialised
 per-kernel-family split of one batch-1 call from HIP events is left to rocprofv3 (scripts/r3_prof_infer.sh).
 python scripts/bench_infer_stages.py"""
 import os, sys
@@ -27,7 +27,7 @@ for rnd in range(3):
             tr = Translator(g, use_graph=True)
             res.setdefault((B, H, stages), []).append(ev_time(lambda: tr.run_phys(x)))
             del tr
-lib.uig_debug_set_strip_stages(0)
+lib.uig_debug_set_strip_stages(2)
 for (B, H, stages), v in sorted(res.items()):
     v = sorted(v)
     print(f"G9 bf16 B={B} {H}x{H} weight stages {stages}: median {v[len(v)//2]:7.3f} ms  min {v[0]:7.3f} ms")

@@ -514,12 +514,14 @@ def test_side_streams_equal_single_stream(graph, monkeypatch):
     m0.close(); m2.close()
 
 
+@pytest.mark.parametrize("staged", [False, True], ids=["one-bucket-per-phase", "staged-backward"])
 @pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
-def test_two_rank_data_parallel_step_equals_full_batch(graph, tmp_path):
+def test_two_rank_data_parallel_step_equals_full_batch(graph, staged, tmp_path):
     """Two ranks (gloo, both on GPU 0; RCCL refuses two ranks per device) each train on one image of a 2-image batch through the
-    product's data-parallel step - backward in stages, a gradient bucket all-reduced behind each stage (between the stage graphs
-    in graph mode), both generator passes' weight gradients in one launch, 1/world folded into Adam - against ONE process training
-    on the full batch.  InstanceNorm is per sample and every loss is a batch mean, so: sum of the ranks' gradients = 2 x the
+    product's data-parallel step - the round-3 default (one all-reduce per optimiser group behind its phase: the generators' runs
+    under the discriminator phase) and the staged form (backward in stages, a gradient bucket all-reduced behind each stage, between
+    the stage graphs in graph mode); both generator passes' weight gradients in one launch, 1/world folded into Adam - against ONE
+    process training on the full batch.  InstanceNorm is per sample and every loss is a batch mean, so: sum of the ranks' gradients = 2 x the
     full-batch gradient, and the parameters agree after two steps; both up to the fp32 summation order.  A bucket reduced before
     its last gradient had landed would show as a missing contribution here (at world size 1 it cannot)."""
     import socket
@@ -530,7 +532,7 @@ def test_two_rank_data_parallel_step_equals_full_batch(graph, tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     outs = [str(tmp_path / f"r{r}.pt") for r in range(2)]
-    procs = [subprocess.Popen([sys.executable, worker, str(r), str(port), outs[r], "1" if graph else "0"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(port), outs[r], "1" if graph else "0", "1" if staged else "0"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(2)]
     # the full-batch reference, in this process, while the ranks run
     torch.manual_seed(31)

@@ -1055,8 +1055,8 @@ def test_strip_persistent_512_row_strip_on_128_wide_maps(B, group):
 @pytest.mark.parametrize("S,cin,cout,B,group", [(64, 256, 256, 1, 0), (64, 256, 256, 3, 1), (16, 64, 128, 2, 0), (32, 128, 256, 5, 2), (24, 192, 128, 1, 0)],
                          ids=["b1-64px-infer", "b3-paired", "one-chunk", "two-chunks-paired", "three-chunks"])
 def test_strip128_deep_weight_prefetch_equals_two_stage_kernel(S, cin, cout, B, group):
-    """Round 3: the 128x128-tile bf16 strip kernel with FOUR weight stages (tiles fetched three K-steps ahead, counted vmcnt: the
-    batch-1 inference path, grids <= 256 blocks) must be bit-identical to the two-stage kernel (same accumulation order), forward
+    """Round 3: the 128x128-tile bf16 strip kernel with FOUR weight stages (tiles fetched three K-steps ahead, counted vmcnt: an opt-in
+    variant, measured slower than two stages at batch 1) must be bit-identical to the two-stage kernel (same accumulation order), forward
     with the fused InstanceNorm statistics and reflect-pad input gradient, and both close to the stock-torch convolution on
     bf16-rounded operands.  Cin = 64 / 128 / 192 / 256: 9, 18, 27, 36 K-steps (the counted wait's tail cases)."""
     u, ops, networks = _mods()
@@ -1080,7 +1080,7 @@ def test_strip128_deep_weight_prefetch_equals_two_stage_kernel(S, cin, cout, B, 
             torch.cuda.synchronize()
             outs[n] = (y.clone(), y._uig_in_partial[0].clone(), dx.clone())
     finally:
-        lib.uig_debug_set_strip_stages(0)
+        lib.uig_debug_set_strip_stages(2)
     for a, b, name in zip(outs[2], outs[4], ("y", "InstanceNorm partial statistics", "dx")):
         assert torch.equal(a, b), f"{name}: four-stage kernel differs from the two-stage kernel"
     g = group if group else B

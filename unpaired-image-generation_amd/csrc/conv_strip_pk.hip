@@ -612,6 +612,7 @@ int uig_launch_strip_pk(const void* x, const void* wp, const float* bias, void* 
                 case 12: return launch_pk<bf16_t, 448, 0, 1, true, false, true>(x, wp, bias, y, d, ntiles, s);
                 case 20: return launch_pk<bf16_t, 448, 5, 1, true, false, true, false, false, 4, true>(x, wp, bias, y, d, ntiles, s);
                 case 21: return launch_pk<bf16_t, 448, 5, 1, true, false, true, false, false, 8, true>(x, wp, bias, y, d, ntiles, s);
+                case 22: return launch_pk<bf16_t, 448, 5, 1, true, false, true, false, false, 4, false>(x, wp, bias, y, d, ntiles, s);
                 default: return launch_pk<bf16_t, 448, 5, 1, true, false, true>(x, wp, bias, y, d, ntiles, s);
             }
         }
@@ -619,6 +620,7 @@ int uig_launch_strip_pk(const void* x, const void* wp, const float* bias, void* 
         switch (g_pk_dm) {      // tuning variants (A/B in one process: scripts/bench_strip_pk.py)
             case 20: return launch_pk<bf16_t, 448, 5, 1, true, false, false, false, false, 4, true>(x, wp, bias, y, d, ntiles, s);   // four issuing waves, packed row table
             case 21: return launch_pk<bf16_t, 448, 5, 1, true, false, false, false, false, 8, true>(x, wp, bias, y, d, ntiles, s);   // eight issuing waves, packed row table
+            case 22: return launch_pk<bf16_t, 448, 5, 1, true, false, false, false, false, 4, false>(x, wp, bias, y, d, ntiles, s);  // four issuing waves, plain row table (spills a few registers per TILE, none in the K loop)
             case 2: return launch_pk<bf16_t, 448, 0, 0, true>(x, wp, bias, y, d, ntiles, s);      // XOR swizzle (for the bank-conflict counters)
             case 4: return launch_pk<bf16_t, 448, 0, 1, false>(x, wp, bias, y, d, ntiles, s);     // no lgkmcnt wait before the barrier
             case 8: return launch_pk<bf16_t, 448, 2, 1, false>(x, wp, bias, y, d, ntiles, s);     // reads of half 0, then the DMAs

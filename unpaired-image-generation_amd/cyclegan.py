@@ -55,11 +55,19 @@ class CycleGAN:
         # generator update (exchange wait, Adam, repack) on its own stream under the discriminator phase (0: after it, on the main
         # stream).  Default: only when gradients are exchanged (the wait for the all-reduce is what it hides); on one GPU the
         # second stream measured slower (see ops.PARALLEL_BACKWARD)
-        self.overlap_update = os.environ.get("UIG_OVERLAP_UPDATE", "1" if self.xchg.active else "0") != "0"
+        # Round 3: OFF by default also under data parallelism (measured at one rank with the exchange forced: 14.39 vs 14.31 ms): the
+        # generators' all-reduce is enqueued on the communication stream behind the generator phase and runs under the whole
+        # discriminator phase anyway; their Adam + repack then run behind the discriminator phase on the main stream, UNDER the
+        # discriminators' all-reduce.
+        self.overlap_update = os.environ.get("UIG_OVERLAP_UPDATE", "0") != "0"
         # data-parallel gradient buckets: the backward pass of each phase is cut into stages and each stage's slice of the flat
         # gradient buffer is all-reduced under the next stage (dp.staged_backward / run_exchange_phase).  One stage (= the
         # single-GPU step, bit for bit) when no collective is issued.
-        self.stage_backward = stage_backward            # None: exactly when collectives run; True / False: forced (tests)
+        # Round 3: NOT staged by default (UIG_DP_STAGED=1 / stage_backward=True turn it on).  The generators' exchange (91 MB) has the
+        # discriminator phase (~3.5 ms) to hide under and the discriminators' (22 MB) the generators' Adam + repack, so cutting the
+        # backward passes only buys what it costs: at one rank with the exchange forced the staged step is 14.59 ms, the un-staged one
+        # 14.31 ms, no exchange 13.90 ms (one box, bench.py --force-comm).
+        self.stage_backward = stage_backward            # None: UIG_DP_STAGED (default 0) when collectives run; True / False: forced
         self.n_stages_G = int(os.environ.get("UIG_DP_STAGES_G", "4"))
         self.n_stages_D = int(os.environ.get("UIG_DP_STAGES_D", "2"))
         self._graphs = None
@@ -72,7 +80,8 @@ class CycleGAN:
     def _finalize_params(self):
         self.grp_G = FlatGroup((self.G_A, self.G_B), self.device)
         self.grp_D = FlatGroup((self.D_A, self.D_B), self.device)
-        staged = (self.xchg.active if self.stage_backward is None else bool(self.stage_backward)) and self.batch_fused and self.paired
+        want = (self.xchg.active and os.environ.get("UIG_DP_STAGED", "0") != "0") if self.stage_backward is None else bool(self.stage_backward)
+        staged = want and self.batch_fused and self.paired
         self.cuts_G = self.G_A.stage_cut_modules(self.n_stages_G) if staged else []
         self.cuts_D = self.D_A.stage_cut_modules(self.n_stages_D) if staged else []
         self.buckets_G = self.grp_G.buckets([self.G_A.param_index_at(i) for i in self.cuts_G])
