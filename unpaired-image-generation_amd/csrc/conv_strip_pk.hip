@@ -128,7 +128,12 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
     };
     const unsigned svl_odd = SWZ ? svl : (unsigned)((l8 * Cin + (ls ^ ((l8 >> 1) | 4)) * E) * (int)sizeof(T));   // XOR form: odd pieces flip bit 2
     auto issue_strip_piece = [&](int j, unsigned sbase, int NS, int region) {  // all arguments wave-uniform
-        const unsigned off = (8 * j + l8 < NS) ? ((j & 1) ? svl_odd : svl) + (unsigned)(8 * j * Cin * (int)sizeof(T)) : 0xFFFFFFFFu;
+        // the lane offset is made opaque here: left visible, the optimiser hoists the 9 (18 with four issuing waves) per-tap offsets
+        // svl + 8 j Cin sizeof(T) out of the chunk loop - they do not depend on the chunk - and carries them through the K loop in as
+        // many registers (the four-issuing-wave variant then spilled; round 3)
+        unsigned sv = (j & 1) ? svl_odd : svl;
+        asm volatile("" : "+v"(sv));
+        const unsigned off = (8 * j + l8 < NS) ? sv + (unsigned)(8 * j * Cin * (int)sizeof(T)) : 0xFFFFFFFFu;
         lds_ptr_t dst = (lds_ptr_t)smem + region * REG + j * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)dst, 16, (int)off, (int)sbase, 0, 0);
     };
@@ -139,9 +144,13 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
     // with all eight waves issuing their three pieces behind the step's barrier, every wave stood there for the whole burst with the matrix
     // pipes empty (in-kernel stamps of the fp8 kernel: ~450 cycles per step).  With NISS = 4 the other wave of every SIMD goes straight to
     // its fragment reads and MFMAs.  NORM keeps 8: its waves normalise the strip pieces they issued themselves.  Measured on this kernel
-    // (scripts/bench_strip_pk.py, variants 20 / 21): forward 69.6 -> 67.9 us, mirror-pixel input gradient 75.3 -> 77.4 us - the packed row
-    // table the variant needs to stay clear of spills costs about what the issuing split gains, so 8 stays the default here (the fp8
-    // kernel, whose row table was packed already, takes 4).
+    // (scripts/bench_strip_pk.py, A/B in one process, bitwise equal): with the row table packed to make room (variants 20 / 21) the
+    // packing costs what the split gains (forward 69.6 -> 67.9 us, mirror-pixel input gradient 75.3 -> 77.4 us); with the PLAIN row
+    // table the variant first spilled 2-13 registers around the tile loop (the few bytes of scratch made the STEP 0.14 ms slower although
+    // every launch was faster) until the strip pieces' per-tap lane offsets were kept from being hoisted out of the chunk loop
+    // (issue_strip_piece): 249 / 254 registers, no scratch.  Forward 71.7 -> 68.6 us (16 images) / 39.0 -> 37.7 (8), mirror-pixel input
+    // gradient 78.1 -> 75.3 / 42.8 -> 42.2; same box, bench.py: dominant launch 70.8 -> 68.4 us (0.437 -> 0.452 of peak), strip family in
+    // the step 0.406 -> 0.417, generator forward 2.380 -> 2.349 ms; the step itself 13.48 -> 13.47 ms (a tie).  Default since.
     static_assert((NISS == 4 || NISS == 8) && (!NORM || NISS == 8), "issuing waves");
     constexpr int WPI = 16 / NISS;                             // weight pieces per issuing wave and step: piece wave + NISS i = rows + 8 NISS i (same swizzle term)
     const unsigned wvl0 = (unsigned)((lr * d.ldw + (ch ^ ((lr >> 1) & 7)) * E) * (int)sizeof(T));
@@ -612,22 +621,23 @@ int uig_launch_strip_pk(const void* x, const void* wp, const float* bias, void* 
                 case 12: return launch_pk<bf16_t, 448, 0, 1, true, false, true>(x, wp, bias, y, d, ntiles, s);
                 case 20: return launch_pk<bf16_t, 448, 5, 1, true, false, true, false, false, 4, true>(x, wp, bias, y, d, ntiles, s);
                 case 21: return launch_pk<bf16_t, 448, 5, 1, true, false, true, false, false, 8, true>(x, wp, bias, y, d, ntiles, s);
-                case 22: return launch_pk<bf16_t, 448, 5, 1, true, false, true, false, false, 4, false>(x, wp, bias, y, d, ntiles, s);
-                default: return launch_pk<bf16_t, 448, 5, 1, true, false, true>(x, wp, bias, y, d, ntiles, s);
+                case 23: return launch_pk<bf16_t, 448, 5, 1, true, false, true>(x, wp, bias, y, d, ntiles, s);                             // eight issuing waves (round 2's form)
+                default: return launch_pk<bf16_t, 448, 5, 1, true, false, true, false, false, 4, false>(x, wp, bias, y, d, ntiles, s);  // four issuing waves
             }
         }
         if (d.dbg != nullptr) return launch_pk<bf16_t, 448, 0, 1, true, true>(x, wp, bias, y, d, ntiles, s);
         switch (g_pk_dm) {      // tuning variants (A/B in one process: scripts/bench_strip_pk.py)
             case 20: return launch_pk<bf16_t, 448, 5, 1, true, false, false, false, false, 4, true>(x, wp, bias, y, d, ntiles, s);   // four issuing waves, packed row table
             case 21: return launch_pk<bf16_t, 448, 5, 1, true, false, false, false, false, 8, true>(x, wp, bias, y, d, ntiles, s);   // eight issuing waves, packed row table
-            case 22: return launch_pk<bf16_t, 448, 5, 1, true, false, false, false, false, 4, false>(x, wp, bias, y, d, ntiles, s);  // four issuing waves, plain row table (spills a few registers per TILE, none in the K loop)
+            case 23: return launch_pk<bf16_t, 448, 5, 1, true>(x, wp, bias, y, d, ntiles, s);                                           // eight issuing waves (round 2's default)
             case 2: return launch_pk<bf16_t, 448, 0, 0, true>(x, wp, bias, y, d, ntiles, s);      // XOR swizzle (for the bank-conflict counters)
             case 4: return launch_pk<bf16_t, 448, 0, 1, false>(x, wp, bias, y, d, ntiles, s);     // no lgkmcnt wait before the barrier
             case 8: return launch_pk<bf16_t, 448, 2, 1, false>(x, wp, bias, y, d, ntiles, s);     // reads of half 0, then the DMAs
             case 9: return launch_pk<bf16_t, 448, 3, 1, false>(x, wp, bias, y, d, ntiles, s);     // all reads up front, then the DMAs
             case 10: return launch_pk<bf16_t, 448, 4, 1, false>(x, wp, bias, y, d, ntiles, s);    // s_setprio around the MFMA clusters
             case 12: return launch_pk<bf16_t, 448, 0, 1, true>(x, wp, bias, y, d, ntiles, s);     // the form before the cross-barrier prefetch (A/B; also switches the mirror kernel back)
-            default: return launch_pk<bf16_t, 448, 5, 1, true>(x, wp, bias, y, d, ntiles, s);     // next step's strip fragments read behind this step's MFMAs
+            // default: next step's strip fragments read behind this step's MFMAs (round 2) + four issuing waves (round 3)
+            default: return launch_pk<bf16_t, 448, 5, 1, true, false, false, false, false, 4, false>(x, wp, bias, y, d, ntiles, s);
         }
     }
     if (d.mirror) return uig_set_error(-1, "conv_strip_pk: mirror pixels are a bf16 path");
