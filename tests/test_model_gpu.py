@@ -352,6 +352,37 @@ def test_train_step_config2_b4_256_bf16_graph_vs_oracle():
     m.close()
 
 
+def test_train_step_config4_b2_512_bf16_graph_vs_same_rounding_oracle():
+    """BASELINE.json configs[3] AT ITS OWN WORKLOAD (round 3): batch 2 at 512x512, 9-block generators, bf16, HIP-graph replay - the
+    configuration whose 128-pixel-wide ResBlock maps run on this round's wide-row weight-gradient kernel and 512-row forward strip.
+    One full train step against the same-rounding CPU emulation of the bf16 step (oracle/lowprec_oracle.LowPrecOracle): 8 losses to
+    1 % [measured <= 1e-3], generated image mean |diff| <= 1e-2 / L-inf <= 0.12, one ResBlock weight gradient relative L2 <= 0.40 and
+    cosine >= 0.93 (why not tighter: see test_train_step_config2_b4_256_bf16_graph_vs_oracle).  PARITY UNPINNED BY THE REFERENCE."""
+    import unpaired_image_generation_amd as u
+    from oracle.lowprec_oracle import LowPrecOracle
+    torch.manual_seed(13)
+    e = LowPrecOracle(n_blocks=9)
+    m = u.CycleGAN(n_blocks=9, dtype=torch.bfloat16, use_graph=True)
+    _load_oracle_weights(m, e)
+    rA, rB = torch.rand(2, 3, 512, 512) * 2 - 1, torch.rand(2, 3, 512, 512) * 2 - 1
+    lm = m.train_step(rA.cuda(), rB.cuda())
+    assert m.graph_active, "the step fell back to eager launches"
+    le = e.train_step(rA, rB)
+    print({k: (round(le[k], 4), round(lm[k], 4)) for k in le})
+    for k in le:
+        assert lm[k] == lm[k] and abs(le[k] - lm[k]) <= 1e-2 * max(1.0, abs(le[k])), (k, le[k], lm[k])
+    fb = u.ops.from_nhwc(m.last_fake_B, 3).cpu()
+    d = (fb - e.last["fake_B"]).abs()
+    print("fake_B vs bf16 emulation: L-inf", float(d.max()), "mean", float(d.mean()))
+    assert float(d.max()) <= 0.12 and float(d.mean()) <= 1e-2
+    mine, theirs = m.G_A[14].b[5].weight.grad.cpu(), e.G_A[14].b[5].weight.grad
+    rel = float((mine - theirs).norm() / theirs.norm())
+    cos = float(torch.nn.functional.cosine_similarity(mine.flatten(), theirs.flatten(), dim=0))
+    print(f"weight gradient G_A ResBlock 5 conv 2: relative L2 vs bf16 emulation {rel:.3e}, cosine {cos:.4f}")
+    assert rel <= 0.40 and cos >= 0.93, (rel, cos)
+    m.close()
+
+
 def test_train_step_256_fp32_vs_committed_golden():
     """SURVEY Appendix B recipe B2 (seed 0, B=1, 256x256, 9 blocks): the 8 first-step losses committed in
     tests/golden/train_step_256_losses.json, reproduced by the exact-f32 HIP path to 2e-4 relative.  Weights and inputs are
