@@ -208,6 +208,7 @@ size_t uig_wgrad_workspace_bytes(int Np, int Cq, int kH, int kW, int splits);
 int uig_wgrad_tile_rows(int Np, int Mw, int dtype);
 void uig_debug_set_wgrad_wide(int on);   /* tuning hook: 0 = never use the 256-row tile */
 void uig_debug_set_wgrad_rows(int on);   /* A/B hook: 0 = never use the image-row kernel of the stride-1 3x3 convs */
+void uig_debug_set_wgrad_rows_s2(int on);          /* image-row weight-gradient kernel, stride-2 form (round 3): 1 (default) / 0 = stride-2 layers on the generic split-K kernel */
 /* 1 if a stride-2 3x3 transposed gather of this shape runs on the phase-fused kernel (conv_tr2.hip): such launches may emit
  * InstanceNorm statistics (in_partial of uig_conv_gather_ex) for 64 output channels too */
 int uig_conv_tr2_applicable(int B, int H, int W, int Cin, int Nrows, int Nstore, int ldc, int dtype);

@@ -1,9 +1,9 @@
 source scripts/r3_run.sh r4d
 step n1 400 python bench.py --config 5 --no-cpu-baseline
-step o1 400 env UIG_MX_ISSUERS=8 python bench.py --config 5 --no-cpu-baseline
+step o1 400 env UIG_DEBUG_HOOKS=mx_issuers=8 python bench.py --config 5 --no-cpu-baseline
 step n2 400 python bench.py --config 5 --no-cpu-baseline
-step o2 400 env UIG_MX_ISSUERS=8 python bench.py --config 5 --no-cpu-baseline
-step bf 400 env UIG_STRIP_PK_VARIANT=23 python bench.py --batch 8 --no-cpu-baseline --no-other-configs
+step o2 400 env UIG_DEBUG_HOOKS=mx_issuers=8 python bench.py --config 5 --no-cpu-baseline
+step bf 400 env UIG_DEBUG_HOOKS=strip_pk=23:0 python bench.py --batch 8 --no-cpu-baseline --no-other-configs
 step bfn 400 python bench.py --batch 8 --no-cpu-baseline --no-other-configs
 python - <<'PY'
 import json

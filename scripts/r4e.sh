@@ -1,8 +1,8 @@
 source scripts/r3_run.sh r4e
-step v20a 400 env UIG_STRIP_PK_VARIANT=20 python bench.py --no-cpu-baseline --no-other-configs
-step v23a 400 env UIG_STRIP_PK_VARIANT=23 python bench.py --no-cpu-baseline --no-other-configs
-step v20b 400 env UIG_STRIP_PK_VARIANT=20 python bench.py --no-cpu-baseline --no-other-configs
-step v23b 400 env UIG_STRIP_PK_VARIANT=23 python bench.py --no-cpu-baseline --no-other-configs
+step v20a 400 env UIG_DEBUG_HOOKS=strip_pk=20:0 python bench.py --no-cpu-baseline --no-other-configs
+step v23a 400 env UIG_DEBUG_HOOKS=strip_pk=23:0 python bench.py --no-cpu-baseline --no-other-configs
+step v20b 400 env UIG_DEBUG_HOOKS=strip_pk=20:0 python bench.py --no-cpu-baseline --no-other-configs
+step v23b 400 env UIG_DEBUG_HOOKS=strip_pk=23:0 python bench.py --no-cpu-baseline --no-other-configs
 python - <<'PY'
 import json
 for f in ("v20a","v23a","v20b","v23b"):

@@ -1,8 +1,8 @@
 source scripts/r3_run.sh r4f
 step n1 400 python bench.py --no-cpu-baseline --no-other-configs
-step o1 400 env UIG_STRIP_PK_VARIANT=23 python bench.py --no-cpu-baseline --no-other-configs
+step o1 400 env UIG_DEBUG_HOOKS=strip_pk=23:0 python bench.py --no-cpu-baseline --no-other-configs
 step n2 400 python bench.py --no-cpu-baseline --no-other-configs
-step o2 400 env UIG_STRIP_PK_VARIANT=23 python bench.py --no-cpu-baseline --no-other-configs
+step o2 400 env UIG_DEBUG_HOOKS=strip_pk=23:0 python bench.py --no-cpu-baseline --no-other-configs
 python - <<'PY'
 import json
 for f in ("n1","o1","n2","o2"):

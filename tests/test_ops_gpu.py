@@ -1089,3 +1089,47 @@ def test_strip128_deep_weight_prefetch_equals_two_stage_kernel(S, cin, cout, B, 
                      for (a, e), l in zip(((0, g), (g, B)), ls) if e > a])
     got = ops.from_nhwc(outs[4][0], cout).float().cpu()
     assert (got - ref).abs().max() <= 1.6e-2 * ref.abs().max()
+
+
+@pytest.mark.parametrize("kind,cin,cout,B,group", [("conv", 128, 256, 3, 0), ("conv", 128, 256, 4, 2), ("convT", 256, 128, 3, 0), ("convT", 256, 128, 5, 2), ("conv", 256, 384, 2, 0)],
+                         ids=["down2", "down2-pair", "up1-convT", "up1-pair-uneven", "256to384"])
+def test_wgrad_row_kernel_stride2_matches_generic_and_oracle(kind, cin, cout, B, group):
+    """Round 3: the stride-2 form of the image-row weight-gradient kernel (down2: Conv2d 128 -> 256 k3 s2 p1 on 128 x 128; up1:
+    ConvTranspose2d 256 -> 128 k3 s2 p1 op1 on 64 x 64 - the same contraction with the maps' roles swapped): a K-step stages one
+    64-pixel row of the small map and the 128-pixel row 2 i + kh - 1 of the large one, the kw taps read its pixels 2 j + kw - 1.
+    Against the generic split-K kernel on the same operands (same products, different fp32 summation order: 2e-5 of max) and against
+    stock torch's weight gradient on the bf16-rounded operands (bf16 products exact in fp32: 1e-4 of max), single and paired launch."""
+    u, ops, networks = _mods()
+    import torch.nn.functional as F
+    lib, dt = u.lib.lib(), torch.bfloat16
+    torch.manual_seed(90 + cin + B)
+    layer = networks.ConvLayer(kind, cin, cout, 3, 2, 1, "zero", dtype=dt, device="cuda")
+    spec = layer.spec
+    hw = 128 if kind == "conv" else 64
+    Ho, Wo = spec.out_hw(hw, hw)
+    x = (torch.rand(B, hw, hw, spec.cin_p, device="cuda") * 2 - 1).to(dt)
+    dy = (torch.randn(B, Ho, Wo, spec.cout_p, device="cuda") * 0.5).to(dt)
+    def run():
+        if group:
+            parts = ops.conv_wgrad_pair_partial(spec, x, dy, group)
+            assert parts is not None
+            return [ops.conv_wgrad(spec, x[:group], dy[:group], partial=parts[0]), ops.conv_wgrad(spec, x[group:], dy[group:], partial=parts[1])]
+        return [ops.conv_wgrad(spec, x, dy)]
+    try:
+        lib.uig_debug_set_wgrad_rows_s2(0)
+        ref = run()
+    finally:
+        lib.uig_debug_set_wgrad_rows_s2(1)
+    got = run()
+    torch.cuda.synchronize()
+    for g_, r_ in zip(got, ref):
+        scale = float(r_.abs().max())
+        assert scale > 0 and float((g_ - r_).abs().max()) <= 2e-5 * scale, f"stride-2 row kernel vs generic: {float((g_ - r_).abs().max())} of {scale}"
+    # stock torch on the same bf16 values
+    xl, dyl = ops.from_nhwc(x, spec.cin).float().cpu(), ops.from_nhwc(dy, spec.cout).float().cpu()
+    w = torch.zeros(spec.weight_shape(), requires_grad=True)
+    segs = ((0, group), (group, B)) if group else ((0, B),)
+    for (a, e), g_ in zip(segs, got):
+        y = F.conv2d(xl[a:e], w, None, 2, 1) if kind == "conv" else F.conv_transpose2d(xl[a:e], w, None, 2, 1, 1)
+        (gw,) = torch.autograd.grad(y, w, dyl[a:e])
+        assert float((g_.cpu() - gw).abs().max()) <= 1e-4 * float(gw.abs().max())

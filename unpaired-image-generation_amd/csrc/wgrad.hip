@@ -362,9 +362,10 @@ extern "C" int uig_wgrad_tile_rows(int Np, int Mw, int dtype) {
 }
 
 // wgrad_rows.hip: stride-1 3x3 "same" convs on 64-pixel rows, bf16
-bool uig_wgrad_rows_applicable(int Mh, int Mw, int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int dtype);
+// (round 3: also the stride-2 3x3 layers with 64-pixel output rows; pad_mode defaults to zero padding for the split-count queries, which do not carry it)
+bool uig_wgrad_rows_applicable(int Mh, int Mw, int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int dtype, int pad_mode = UIG_PAD_ZERO);
 int uig_wgrad_rows_tiles(int Np, int Cq);
-int uig_launch_wgrad_rows(const void* P, const void* Q, float* ws, int B, int H, int W, int Np, int Cq, int pad_mode, int splits, int group_images, hipStream_t s);
+int uig_launch_wgrad_rows(const void* P, const void* Q, float* ws, int B, int H, int W, int Np, int Cq, int pad_mode, int splits, int group_images, hipStream_t s, int stride = 1);
 // wgrad_head.hip: 7x7 stride-1 pad-3 convs with 64 input and <= 8 (padded) output channels, bf16
 bool uig_wgrad_head_applicable(int Mh, int Mw, int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int dtype);
 int uig_launch_wgrad_head(const void* P, const void* Q, float* ws, int B, int H, int W, int Np, int pad_mode, int splits, int group_images, hipStream_t s);
@@ -427,9 +428,9 @@ static int wgrad_partial_impl(const void* P, const void* Q, float* workspace, in
     } else {
         d.Mper = ((M_net + splits - 1) / splits + 63) / 64 * 64;
     }
-    if (r2 == nullptr && uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype) &&
+    if (r2 == nullptr && uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype, pad_mode) &&
         splits <= (group_images > 0 ? std::min(group_images, B - group_images) : B) * Mh)
-        return uig_launch_wgrad_rows(P, Q, workspace, B, Mh, Mw, Np, Cq, pad_mode, splits, group_images, s);
+        return uig_launch_wgrad_rows(P, Q, workspace, B, Mh, Mw, Np, Cq, pad_mode, splits, group_images, s, stride);
     if (r2 == nullptr && uig_wgrad_head_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype) &&
         splits <= (group_images > 0 ? std::min(group_images, B - group_images) : B) * Mh)
         return uig_launch_wgrad_head(P, Q, workspace, B, Mh, Mw, Np, pad_mode, splits, group_images, s);
@@ -489,7 +490,7 @@ extern "C" int uig_wgrad_partial_pair(const void* P, const void* Q, float* works
 // 122 -> 102 us, stem 270 -> 248 us.  uig_wgrad_pair2_splits returns 0 where the two launches must stay.
 // Workspace: [2][splits][Np][kH*kW*Cq] floats, reduced like uig_wgrad_partial_pair's.
 int uig_launch_wgrad_rows_runs(const void* P, const void* Q, const void* P2, const void* Q2, float* ws, int B1, int B2, int H, int W, int Np, int Cq,
-                               int pad_mode, int splits, const int* imgs, const int* img0, const int* sel, hipStream_t s);
+                               int pad_mode, int splits, const int* imgs, const int* img0, const int* sel, hipStream_t s, int stride = 1);
 // generic kernel, two runs: S splits per network in all (the grid of uig_wgrad_pair_splits for the whole batch), divided between
 // the runs in proportion to their pixels, at least one each
 static void pair2_generic_splits(int B1, int g1, int B2, int g2, int swap2, int Mh, int Mw, int Np, int Cq, int kH, int kW, int dtype,
@@ -530,7 +531,7 @@ extern "C" int uig_wgrad_partial_pair2(const void* P, const void* Q, const void*
         UIG_CHECK_ARG(splits == want, "uig_wgrad_partial_pair2: splits %d != uig_wgrad_pair2_splits() = %d", splits, want);
         return uig_launch_wgrad_head_runs(P, Q, P2, Q2, workspace, B1, g1, B2, g2, swap2, Mh, Mw, Np, pad_mode, splits, (hipStream_t)stream);
     }
-    if (!uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype)) {
+    if (!uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype, pad_mode)) {
         // generic split-K kernel: the split between the two runs is fixed by the shape, so `splits` must be the queried value
         UIG_CHECK_ARG(splits == want, "uig_wgrad_partial_pair2: splits %d != uig_wgrad_pair2_splits() = %d", splits, want);
         int s_all = 0, s0 = 0;
@@ -544,7 +545,7 @@ extern "C" int uig_wgrad_partial_pair2(const void* P, const void* Q, const void*
     const int imgs[4] = {g1, swap2 ? B2 - g2 : g2, B1 - g1, swap2 ? g2 : B2 - g2};
     const int img0[4] = {0, swap2 ? g2 : 0, g1, swap2 ? 0 : g2};
     const int sel[4] = {0, 1, 0, 1};
-    return uig_launch_wgrad_rows_runs(P, Q, P2, Q2, workspace, B1, B2, Mh, Mw, Np, Cq, pad_mode, splits, imgs, img0, sel, (hipStream_t)stream);
+    return uig_launch_wgrad_rows_runs(P, Q, P2, Q2, workspace, B1, B2, Mh, Mw, Np, Cq, pad_mode, splits, imgs, img0, sel, (hipStream_t)stream, stride);
 }
 
 static int wgrad_reduce_impl(const float* workspace, float* dW, int Np, int Cq, int taps, int splits, int D0, int D1, int accumulate,

@@ -22,6 +22,14 @@
 // two extra rows (64, 65) behind the X tile by ONE more DMA piece per K-step (wave 7; its counted vmcnt waits are one higher per
 // stage in flight), with the reflection / zero decision made on the scalar side per step, so the per-lane fragment address table
 // stays one table: pixel -1 -> row 64, pixel 64 -> row 65.  On 64-wide rows the original form (in-tile reflection) is kept.
+//
+// Round 3, S2: the STRIDE-2 3x3 pad-1 layers with 128-multiples of channels on both sides and 64-pixel output rows - down2
+// (Conv2d 128 -> 256) and up1 (ConvTranspose2d 256 -> 128, whose weight gradient is the same contraction with the roles of the two
+// maps swapped) at 256 x 256 - which ran on the generic split-K kernel at ~390 TFLOP/s.  P is the SMALL map (64-pixel rows), Q the
+// large one (128-pixel rows): a K-step stages one P row [64 px][128 ch] and the Q row 2 i + kh - 1 [128 px][128 ch] (zeros for row -1)
+// and the three kw taps read its pixels 2 j + kw - 1 (pixel -1 = the zero row): 131 FLOP per staged byte.  48 KB per stage, so three
+// stages instead of four (the DMAs of step ks + 2 are issued at the START of step ks's second phase: one full step of flight); the Q
+// tile's XOR swizzle is by ((row >> 1) & 7) so that the same-parity rows a tap reads stay conflict-free.
 #include "uig_common.h"
 #include <algorithm>
 #include <type_traits>
@@ -29,6 +37,7 @@
 struct WgRowsDesc {
     int B, H, Np, Cq, pad_mode;
     int W, S;                // image row width (a multiple of 64) and its 64-pixel segments per row; a K-step = one segment
+    int Hq, Wq;              // S2: the large map's size (2 H x 128); otherwise H x W
     int ncols;               // 9 * Cq
     int rows_total;          // B * H * S K-steps ("rows" below = K-steps: image rows on 64-wide maps)
     int ntc, ntiles, splits; // ci tiles, tiles per network = (Np/128) * ntc * 3
@@ -48,17 +57,20 @@ namespace {
 constexpr int WR_W = 64;                       // pixels per image row = pixels per K-step
 constexpr int WR_TILE = 64 * 256;              // one staged operand tile: 64 pixel rows x 128 channels bf16
 constexpr int WR_NST = 4;
-constexpr int wr_xtile(bool halo) { return halo ? 68 * 256 : WR_TILE; }             // HALO: + rows 64 (left neighbour), 65 (right), 66-67 unused
-constexpr int wr_stage(bool halo) { return WR_TILE + wr_xtile(halo) + 256; }        // dY tile | X tile | one zero row (zero padding of the X columns)
+constexpr int wr_xtile(bool halo, bool s2 = false) { return s2 ? 128 * 256 : (halo ? 68 * 256 : WR_TILE); }   // HALO: + rows 64 (left neighbour), 65 (right), 66-67 unused; S2: a 128-pixel row
+constexpr int wr_stage(bool halo, bool s2 = false) { return WR_TILE + wr_xtile(halo, s2) + 256; }        // dY tile | X tile | one zero row (zero padding of the X columns)
+constexpr int wr_nst(bool s2) { return s2 ? 3 : WR_NST; }
 }
 
-template <bool HALO>
+template <bool HALO, bool S2 = false>
 __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __restrict__ P, const bf16_t* __restrict__ Q,
                                                                const bf16_t* __restrict__ P2, const bf16_t* __restrict__ Q2,
                                                                float* __restrict__ part, const WgRowsDesc d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) unsigned char* lds_ptr_t;
-    constexpr int WR_STAGE = wr_stage(HALO), XT0 = WR_TILE, ZROW = WR_TILE + wr_xtile(HALO);      // stage-relative offsets: X tile, zero row
+    static_assert(!(HALO && S2), "stride-2 rows are 64 pixels wide");
+    constexpr int WR_STAGE = wr_stage(HALO, S2), XT0 = WR_TILE, ZROW = WR_TILE + wr_xtile(HALO, S2);      // stage-relative offsets: X tile, zero row
+    constexpr int NST = wr_nst(S2);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -80,7 +92,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
     const int nk = row_end - row_begin;
 
     // zero rows (one per stage)
-    if (tid < WR_NST * 16) *reinterpret_cast<u32x4_t*>(smem + (tid >> 4) * WR_STAGE + ZROW + (tid & 15) * 16) = u32x4_t{0u, 0u, 0u, 0u};
+    if (tid < NST * 16) *reinterpret_cast<u32x4_t*>(smem + (tid >> 4) * WR_STAGE + ZROW + (tid & 15) * 16) = u32x4_t{0u, 0u, 0u, 0u};
 
     // ---- DMA: wave w stages pieces w and w+8 (rows 4w..4w+3 and +32) of both tiles
     const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(P), 0, d.p_bytes, 0x00020000);
@@ -89,8 +101,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
     const __amdgpu_buffer_rsrc_t rsQ2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Q2 ? Q2 : Q), 0, Q2 ? d.q2_bytes : 0u, 0x00020000);
     const int ra = 4 * wave + (lane >> 4);                            // pixel (LDS row) this lane fills in piece w
     const int chunk = (lane & 15) ^ ((ra & 7) << 1);                  // source chunk for LDS slot lane&15 (same for row ra+32)
+    const int chunkq = S2 ? ((lane & 15) ^ (((ra >> 1) & 7) << 1)) : chunk;      // S2: the Q tile is swizzled by the row PAIR (same for rows ra + 32 k)
     const unsigned voffP = (unsigned)((ra * d.Np + n_base + chunk * 8) * 2);
-    const unsigned voffQ = (unsigned)((ra * d.Cq + ci_base + chunk * 8) * 2);
+    const unsigned voffQ = (unsigned)((ra * d.Cq + ci_base + chunkq * 8) * 2);
     const bool refl = d.pad_mode == UIG_PAD_REFLECT;
     // (tensor, image, row, segment) of the next K-step to issue: the network's steps are run 2*net followed by run 2*net+1 (whole images)
     const int run_a = 2 * net, a_rows = d.run_rows[run_a];
@@ -106,11 +119,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
     const int hq = lane >> 4;
     const unsigned hchunk = (unsigned)(((lane & 15) ^ ((hq & 7) << 1)) * 16 + ci_base * 2);   // row 64 + hq: swizzle by 2 * ((64 + hq) & 7) = 2 * hq
     auto issue = [&](int stage) {
-        const int hi = ii + kh - 1;
-        const bool valid = refl | ((unsigned)hi < (unsigned)d.H);
-        const int hr = refl ? reflect_idx(hi, d.H) : (valid ? hi : 0);
+        const int hi = S2 ? 2 * ii + kh - 1 : ii + kh - 1;
+        const bool valid = (!S2 && refl) | ((unsigned)hi < (unsigned)d.Hq);
+        const int hr = (!S2 && refl) ? reflect_idx(hi, d.H) : (valid ? hi : 0);
         const int sP = __builtin_amdgcn_readfirstlane((int)(((unsigned)(ib * d.H + ii) * (unsigned)d.W + (unsigned)(sg * WR_W)) * 2u * (unsigned)d.Np));
-        const int sQ = __builtin_amdgcn_readfirstlane((int)(((unsigned)(ib * d.H + hr) * (unsigned)d.W + (unsigned)(sg * WR_W)) * 2u * (unsigned)d.Cq));
+        const int sQ = __builtin_amdgcn_readfirstlane((int)(((unsigned)(ib * d.Hq + hr) * (unsigned)d.Wq + (unsigned)(sg * WR_W)) * 2u * (unsigned)d.Cq));
         const unsigned vq = valid ? voffQ : 0xFFFFFFFFu;              // zero-padded row: out-of-range offset -> zeros
         lds_ptr_t dst = (lds_ptr_t)smem + stage * WR_STAGE + wave * 1024;
         if (__builtin_amdgcn_readfirstlane(sel) == 0) {               // block-uniform
@@ -120,6 +133,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(dst + XT0), 16, (int)vq, sQ, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(dst + XT0 + 8192), 16, (int)vq,
                                                      sQ + 32 * d.Cq * 2, 0, 0);
+            if constexpr (S2) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(dst + XT0 + 2 * 8192), 16, (int)vq,
+                                                         sQ + 64 * d.Cq * 2, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(dst + XT0 + 3 * 8192), 16, (int)vq,
+                                                         sQ + 96 * d.Cq * 2, 0, 0);
+            }
         } else {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP2, (__attribute__((address_space(3))) void*)dst, 16, (int)voffP, sP, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP2, (__attribute__((address_space(3))) void*)(dst + 8192), 16, (int)voffP,
@@ -127,6 +146,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ2, (__attribute__((address_space(3))) void*)(dst + XT0), 16, (int)vq, sQ, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ2, (__attribute__((address_space(3))) void*)(dst + XT0 + 8192), 16, (int)vq,
                                                      sQ + 32 * d.Cq * 2, 0, 0);
+            if constexpr (S2) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ2, (__attribute__((address_space(3))) void*)(dst + XT0 + 2 * 8192), 16, (int)vq,
+                                                         sQ + 64 * d.Cq * 2, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ2, (__attribute__((address_space(3))) void*)(dst + XT0 + 3 * 8192), 16, (int)vq,
+                                                         sQ + 96 * d.Cq * 2, 0, 0);
+            }
         }
         if constexpr (HALO) {
             if (wave == 7) {                                          // wave-uniform: one more piece per K-step from this wave (its vmcnt counts differ)
@@ -163,16 +188,17 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
     for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-            const int pix = 16 * gq + k0 + kw - 1;
-            const bool inb = (unsigned)pix < (unsigned)WR_W;
+            const int pix = S2 ? 2 * (16 * gq + k0) + kw - 1 : 16 * gq + k0 + kw - 1;      // S2: pixel of the 128-pixel Q row (-1 only for kw = 0, j = 0)
+            const bool inb = S2 ? pix >= 0 : (unsigned)pix < (unsigned)WR_W;
             // HALO: the segment's neighbours sit in rows 64 / 65 (already reflected / zeroed by the DMA that staged them)
-            const int row = HALO ? (pix < 0 ? 64 : (pix >= WR_W ? 65 : pix)) : (refl ? reflect_idx(pix, WR_W) : (inb ? pix : 0));
-            const bool zero = !HALO && !refl && !inb;
+            const int row = S2 ? (inb ? pix : 0) : (HALO ? (pix < 0 ? 64 : (pix >= WR_W ? 65 : pix)) : (refl ? reflect_idx(pix, WR_W) : (inb ? pix : 0)));
+            const bool zero = S2 ? !inb : (!HALO && !refl && !inb);
+            const int swz = S2 ? (((row >> 1) & 7) << 1) : ((row & 7) << 1);
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const int cidx = wc * 4 + 2 * a + (pp >> 1);
                 qoff[kw][gq][a] = zero ? (unsigned)(ZROW + ((cidx & 15) << 4) + (pp & 1) * 8)
-                                       : (unsigned)(XT0 + row * 256 + ((cidx ^ ((row & 7) << 1)) << 4) + (pp & 1) * 8);
+                                       : (unsigned)(XT0 + row * 256 + ((cidx ^ swz) << 4) + (pp & 1) * 8);
             }
         }
 
@@ -240,10 +266,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
 #endif
     if (nk > 0) issue(0);
     if (nk > 1) issue(1);
-    if (nk > 2) issue(2);
+    if (!S2 && nk > 2) issue(2);
     if (nk > 0) {
-        // stages allowed to stay in flight: 2 / 1 / 0 (4 pieces per stage from every wave; 5 from wave 7 with HALO)
-        if (HALO && wave == 7) {
+        // stages allowed to stay in flight: 2 / 1 / 0 (4 pieces per stage from every wave; 5 from wave 7 with HALO); S2: 1 / 0 (6 pieces)
+        if constexpr (S2) {
+            if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (HALO && wave == 7) {
             if (nk > 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             else if (nk > 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -257,7 +286,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
         for (int c = 0; c < 5; ++c) read_chunk(bf0, af0, lds0, std::integral_constant<int, 0>{}, c);
     }
     for (int ks = 0; ks < nk; ++ks) {
-        const unsigned st = lds0 + (unsigned)((ks % WR_NST) * WR_STAGE);
+        const unsigned st = lds0 + (unsigned)((ks % NST) * WR_STAGE);
         frags_ready(bf0, af0);                             // issued half a step ago: no stall
 #pragma unroll
         for (int gi = 0; gi < 6; ++gi) {
@@ -273,10 +302,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
 #ifdef UIG_X_STAMP
             const unsigned long long w0 = __builtin_amdgcn_s_memtime();
 #endif
-            if (ks + 2 < nk) {                                                      // stage ks+1 landed; stage ks+2 may still fly
+            if (!S2 && ks + 2 < nk) {                                               // stage ks+1 landed; stage ks+2 may still fly
                 if (HALO && wave == 7) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // S2: stage ks+2 is only issued behind this barrier
 #ifdef UIG_X_STAMP
             const unsigned long long w1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -286,7 +315,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
             xw_dma += w1 - w0; xw_bar += w2 - w1;
 #endif
         }
-        const unsigned stn = lds0 + (unsigned)(((ks + 1) % WR_NST) * WR_STAGE);
+        const unsigned stn = lds0 + (unsigned)(((ks + 1) % NST) * WR_STAGE);
+        if constexpr (S2) {                                    // three stages: stage (ks + 2) % 3 = the one step ks - 1 read, retired by the barrier above
+            if (ks + 2 < nk) issue((ks + 2) % NST);
+        }
 #pragma unroll
         for (int gi = 0; gi < 6; ++gi) {
             __builtin_amdgcn_sched_barrier(0);
@@ -294,7 +326,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_rows3_kernel(const bf16_t* __res
             __builtin_amdgcn_sched_barrier(0);
             if (more && gi < 5) read_chunk(bf0, af0, stn, std::integral_constant<int, 0>{}, gi);
 #ifndef UIG_X_NODMA
-            if (gi == 4 && ks + 3 < nk) issue((ks + 3) % WR_NST);
+            if (!S2 && gi == 4 && ks + 3 < nk) issue((ks + 3) % WR_NST);
 #endif
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -330,9 +362,13 @@ static int g_wgrad_rows = 1;    // 1 = use this kernel where it applies, 0 = nev
 extern "C" void uig_debug_set_wgrad_rows(int on) { g_wgrad_rows = on; }
 
 // 1 if uig_wgrad_partial runs this launch on the row kernel
-bool uig_wgrad_rows_applicable(int Mh, int Mw, int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int dtype) {
-    return g_wgrad_rows && dtype == UIG_BF16 && kH == 3 && kW == 3 && stride == 1 && pad == 1 && Mh == Hq && Mw == Wq &&
-           Mw % WR_W == 0 && Mw <= 1024 && (g_wgrad_rows != 2 || Mw == WR_W) && Np % 128 == 0 && Cq % 128 == 0 && Hq >= 2;      // hook value 2: 64-wide rows only (A/B)
+static int g_wgrad_rows_s2 = 1; // 1 = the stride-2 form too (round 3), 0 = stride-2 layers stay on the generic kernel (A/B and parity hook)
+extern "C" void uig_debug_set_wgrad_rows_s2(int on) { g_wgrad_rows_s2 = on; }
+bool uig_wgrad_rows_applicable(int Mh, int Mw, int Np, int Hq, int Wq, int Cq, int kH, int kW, int stride, int pad, int dtype, int pad_mode) {
+    if (!(g_wgrad_rows && dtype == UIG_BF16 && kH == 3 && kW == 3 && pad == 1 && Np % 128 == 0 && Cq % 128 == 0 && Hq >= 2)) return false;
+    if (stride == 2)            // S2: 64-pixel rows of the small map against 128-pixel rows of the large one, zero padding
+        return g_wgrad_rows_s2 && pad_mode == UIG_PAD_ZERO && Mw == WR_W && Hq == 2 * Mh && Wq == 2 * Mw;
+    return stride == 1 && Mh == Hq && Mw == Wq && Mw % WR_W == 0 && Mw <= 1024 && (g_wgrad_rows != 2 || Mw == WR_W);      // hook value 2: 64-wide rows only (A/B)
 }
 
 int uig_wgrad_rows_tiles(int Np, int Cq) { return (Np / 128) * (Cq / 128) * 3; }
@@ -341,37 +377,42 @@ int uig_wgrad_rows_tiles(int Np, int Cq) { return (Np / 128) * (Cq / 128) * 3; }
 // at image img0[r] of its tensor; runs 0, 1 are network 0's, runs 2, 3 network 1's (one network: runs 2, 3 empty).
 // B1 / B2 = images in (P, Q) / (P2, Q2) (for the range checks of the buffer descriptors).
 int uig_launch_wgrad_rows_runs(const void* P, const void* Q, const void* P2, const void* Q2, float* ws, int B1, int B2, int H, int W, int Np, int Cq,
-                               int pad_mode, int splits, const int* imgs, const int* img0, const int* sel, hipStream_t s) {
+                               int pad_mode, int splits, const int* imgs, const int* img0, const int* sel, hipStream_t s, int stride) {
     WgRowsDesc d{};
     int total = 0;
     const int S = W / WR_W;
-    d.W = W; d.S = S;
+    const bool s2 = stride == 2;                      // H x W = the SMALL map (P); Q is 2 H x 2 W
+    if (s2 && (W != WR_W || pad_mode != UIG_PAD_ZERO)) return uig_set_error(-1, "wgrad(rows, stride 2): 64-pixel rows and zero padding only");
+    d.W = W; d.S = S; d.Hq = s2 ? 2 * H : H; d.Wq = s2 ? 2 * W : W;
     for (int r = 0; r < 4; ++r) { d.run_rows[r] = imgs[r] * H * S; d.run_img0[r] = img0[r]; d.run_sel[r] = sel[r]; total += imgs[r]; }
     const bool two = imgs[2] + imgs[3] > 0;
     d.group_rows = two ? d.run_rows[0] + d.run_rows[1] : 0;
     d.B = total; d.H = H; d.Np = Np; d.Cq = Cq; d.pad_mode = pad_mode; d.ncols = 9 * Cq; d.rows_total = total * H * S;
     d.ntc = Cq / 128; d.ntiles = uig_wgrad_rows_tiles(Np, Cq); d.splits = splits;
-    d.p_bytes = (unsigned)((long)B1 * H * W * Np * 2); d.q_bytes = (unsigned)((long)B1 * H * W * Cq * 2);
-    d.p2_bytes = (unsigned)((long)B2 * H * W * Np * 2); d.q2_bytes = (unsigned)((long)B2 * H * W * Cq * 2);
-    if ((long)std::max(B1, B2) * H * W * std::max(Np, Cq) * 2 >= (1L << 32) - 64) return uig_set_error(-1, "wgrad(rows): operand larger than 4 GiB");
+    const long qpix = (long)d.Hq * d.Wq;
+    d.p_bytes = (unsigned)((long)B1 * H * W * Np * 2); d.q_bytes = (unsigned)((long)B1 * qpix * Cq * 2);
+    d.p2_bytes = (unsigned)((long)B2 * H * W * Np * 2); d.q2_bytes = (unsigned)((long)B2 * qpix * Cq * 2);
+    if ((long)std::max(B1, B2) * std::max((long)H * W * Np, qpix * Cq) * 2 >= (1L << 32) - 64) return uig_set_error(-1, "wgrad(rows): operand larger than 4 GiB");
     const bool halo = S > 1;
-    const size_t smem = (size_t)WR_NST * wr_stage(halo);
-    static SmemAttrOnce attr0, attr1;
+    const size_t smem = (size_t)wr_nst(s2) * wr_stage(halo, s2);
+    static SmemAttrOnce attr0, attr1, attr2;
     {
-        hipError_t e = halo ? attr1.ensure(reinterpret_cast<const void*>(wgrad_rows3_kernel<true>), smem)
+        hipError_t e = s2 ? attr2.ensure(reinterpret_cast<const void*>(wgrad_rows3_kernel<false, true>), smem)
+                     : halo ? attr1.ensure(reinterpret_cast<const void*>(wgrad_rows3_kernel<true>), smem)
                             : attr0.ensure(reinterpret_cast<const void*>(wgrad_rows3_kernel<false>), smem);
         if (e != hipSuccess) return uig_set_error((int)e, "wgrad(rows): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     }
     const dim3 grid(d.ntiles * splits * (two ? 2 : 1));
-    if (halo) hipLaunchKernelGGL(wgrad_rows3_kernel<true>, grid, dim3(512), smem, s, (const bf16_t*)P, (const bf16_t*)Q, (const bf16_t*)P2, (const bf16_t*)Q2, ws, d);
+    if (s2) hipLaunchKernelGGL((wgrad_rows3_kernel<false, true>), grid, dim3(512), smem, s, (const bf16_t*)P, (const bf16_t*)Q, (const bf16_t*)P2, (const bf16_t*)Q2, ws, d);
+    else if (halo) hipLaunchKernelGGL(wgrad_rows3_kernel<true>, grid, dim3(512), smem, s, (const bf16_t*)P, (const bf16_t*)Q, (const bf16_t*)P2, (const bf16_t*)Q2, ws, d);
     else hipLaunchKernelGGL(wgrad_rows3_kernel<false>, grid, dim3(512), smem, s, (const bf16_t*)P, (const bf16_t*)Q, (const bf16_t*)P2, (const bf16_t*)Q2, ws, d);
     UIG_LAUNCH_CHECK("uig_wgrad_partial(rows)");
     return 0;
 }
 
 int uig_launch_wgrad_rows(const void* P, const void* Q, float* ws, int B, int H, int W, int Np, int Cq, int pad_mode, int splits,
-                          int group_images, hipStream_t s) {
+                          int group_images, hipStream_t s, int stride) {
     const int imgs[4] = {group_images > 0 ? group_images : B, 0, group_images > 0 ? B - group_images : 0, 0};
     const int img0[4] = {0, 0, group_images, 0}, sel[4] = {0, 0, 0, 0};
-    return uig_launch_wgrad_rows_runs(P, Q, nullptr, nullptr, ws, B, 0, H, W, Np, Cq, pad_mode, splits, imgs, img0, sel, s);
+    return uig_launch_wgrad_rows_runs(P, Q, nullptr, nullptr, ws, B, 0, H, W, Np, Cq, pad_mode, splits, imgs, img0, sel, s, stride);
 }

@@ -62,6 +62,7 @@ SIGNATURES = {
     "uig_wgrad_tile_rows": (_i, [_i, _i, _i]),
     "uig_debug_set_wgrad_wide": (None, [_i]),
     "uig_debug_set_wgrad_rows": (None, [_i]),
+    "uig_debug_set_wgrad_rows_s2": (None, [_i]),
     "uig_debug_set_wgrad_head": (None, [_i]),
     "uig_debug_set_gemv": (None, [_i]),
     "uig_debug_set_cin8": (None, [_i]),

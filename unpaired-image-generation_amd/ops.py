@@ -33,10 +33,6 @@ FUSE_BWD_STATS = os.environ.get("UIG_FUSE_BWD_STATS", "0") != "0"
 MX_DGRAD_MIRROR = os.environ.get("UIG_MX_DGRAD_MIRROR", "1") != "0"   # fp8 layers: reflect-pad input gradient in one launch (mirror pixels re-quantised in LDS) instead of fp8 main term + bf16 border GEMM
 FUSE_MX_QUANT = os.environ.get("UIG_FUSE_MX_QUANT", "1") != "0"            # fp8 path: MX quantisation of activations / gradients inside the InstanceNorm launches
 # ResBlock: conv2 applies the InstanceNorm + ReLU in front of it to its own input strip (NormConvFn): no apply pass between the block's two convolutions
-if os.environ.get("UIG_STRIP_PK_VARIANT"):                   # A/B of the persistent strip kernel's tuning variants from outside the process (e.g. 23 = eight issuing waves)
-    L.lib().uig_debug_set_strip_pk(int(os.environ["UIG_STRIP_PK_VARIANT"]), 0)
-if os.environ.get("UIG_MX_ISSUERS"):                         # A/B of the fp8 kernel's DMA-issuing waves from outside the process (4 default, 8 = round 2's form)
-    L.lib().uig_debug_set_mx_issuers(int(os.environ["UIG_MX_ISSUERS"]))
 NORM_CONV = os.environ.get("UIG_NORM_CONV", "0") != "0"      # OFF by default: measured slower (13.64 vs 13.48 ms per step; g_fwd 2.45 vs 2.34 ms) - see DESIGN.md
 COMBINE_PASS_WGRAD = os.environ.get("UIG_COMBINE_PASS_WGRAD", "1") != "0"  # one weight-gradient launch per ResBlock conv pair for BOTH generator passes of a step
 _SIDE_STREAMS = {}
