@@ -276,6 +276,12 @@ int uig_pack_weight(const float* w, void* wp, int D0, int D1, int kH, int kW, in
  * work_end.  rows_padded must equal the real row count (only the column dimension is zero padded); taps <= 64. */
 int uig_pack_tiles(int D0, int D1, int kH, int kW, int row_dim, int rows_padded, int cols_padded);
 int uig_pack_weights_multi(const void* items_dev, int nitems, int64_t total_work, int dtype, void* stream);
+/* The same with BOTH kernel-side operands of a layer from one pass over its fp32 weights (round 3).  56-byte records
+ * {const float* w; void* dst; void* dst2; int D0, D1, taps, row_dim, cols_padded, cols2_padded; int64 work_end}: dst has rows = torch
+ * dim row_dim and its columns padded to cols_padded, dst2 rows = the other dim, columns padded to cols2_padded; work_end = inclusive
+ * prefix sum of uig_pack_tiles2(...). */
+int uig_pack_tiles2(int D0, int D1, int kH, int kW, int row_dim, int cols_padded, int cols2_padded);
+int uig_pack_weights_multi2(const void* items_dev, int nitems, int64_t total_work, int dtype, void* stream);
 
 /* aten::instance_norm(use_input_stats=True, weight=None, eps) fused with ReLU / LeakyReLU and residual add:
  *   y = act((x - mean_bc) * rstd_bc) + (residual ? residual : 0);  stats fp32[B*C*2] = (mean, rstd) saved for bwd.

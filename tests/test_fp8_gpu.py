@@ -217,3 +217,36 @@ def test_train_step_config5_b8_256_fp8_graph_vs_same_rounding_oracle():
     for name, (rel, cos) in rels.items():
         assert rel <= TOL_GRAD and cos >= TOL_GRAD_COS, (name, rel, cos)
     m.close()
+
+
+def test_mx_quantize_multi_equals_per_layer_quantiser():
+    """Round 3: the one-launch MX quantisation of all fp8 weight operands (uig_mx_quantize_multi over a device table of records, a block
+    finds its record by bisection on a block prefix sum) against the per-layer quantiser and the CPU restatement: e4m3 bytes and E8M0
+    scale bytes identical, for layers of different sizes (so that records have different block counts) and a mixed fp8 / bf16 set."""
+    u, ops, networks = _mods()
+    from oracle import mx_fp8 as M
+    torch.manual_seed(77)
+    dt = torch.bfloat16
+    layers = [networks.ConvLayer("conv", 256, 256, 3, 1, 1, "reflect", dtype=dt, device="cuda"),
+              networks.ConvLayer("conv", 128, 384, 3, 1, 1, "reflect", dtype=dt, device="cuda"),
+              networks.ConvLayer("conv", 64, 128, 3, 2, 1, "zero", dtype=dt, device="cuda"),          # stays bf16
+              networks.ConvLayer("conv", 128, 128, 3, 1, 1, "zero", dtype=dt, device="cuda")]
+    with torch.no_grad():
+        for i, l in enumerate(layers):
+            l.weight.mul_(10.0 ** (i - 1))            # different magnitudes: different scale bytes per record
+    for i in (0, 1, 3):
+        layers[i].enable_fp8()
+    ops.MultiPacker(layers).run()
+    torch.cuda.synchronize()
+    got = [(l.wq_fwd.clone(), l.ws_fwd.clone(), l.wq_dgrad.clone(), l.ws_dgrad.clone()) for l in layers if l.fp8]
+    for l in layers:
+        if l.fp8:
+            for t in (l.wq_fwd, l.ws_fwd, l.wq_dgrad, l.ws_dgrad):
+                t.zero_()
+            l.quantize_packed()                         # per-layer launches on the packed operands the multi launch also read
+    torch.cuda.synchronize()
+    for g, l in zip(got, [l for l in layers if l.fp8]):
+        for a, b, name in zip(g, (l.wq_fwd, l.ws_fwd, l.wq_dgrad, l.ws_dgrad), ("wq_fwd", "ws_fwd", "wq_dgrad", "ws_dgrad")):
+            assert torch.equal(a, b), name
+        qr, sr = M.mx_quantize(l.wp_fwd.cpu())
+        assert torch.equal(g[0].cpu().view(qr.shape), qr) and torch.equal(g[1].cpu().view(sr.shape), sr)

@@ -119,6 +119,98 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackItem*
         __syncthreads();
     }
 }
+// Round 3: BOTH kernel-side operands of a layer from ONE pass over its fp32 weights (the forward and the input-gradient operand are
+// the two transpositions of the same tile: [d0][tap][d1 chunk] and [d1][tap][d0 chunk]).  The two-record form read every weight twice
+// (273 MB moved per generator pack, 83 us); this one reads it once.  Record: the first operand as in PackItem (row_dim, cols_p), the
+// second with the other row_dim; the tile grid covers the union of both operands' padded ranges.
+struct PackItem2 {
+    const float* w; void* dst; void* dst2;
+    int D0, D1, taps, row_dim, cols_p, cols2_p;          // dst: rows = dim row_dim, columns padded to cols_p; dst2: rows = the other dim, columns padded to cols2_p
+    long work_end;
+};
+static_assert(sizeof(PackItem2) == 56, "PackItem2 layout is mirrored by the Python host code");
+static __host__ __device__ inline void pack2_ranges(int D0, int D1, int row_dim, int cols_p, int cols2_p, int* c0, int* c1) {
+    // operand 1 pads the dimension that is NOT its row; operand 2 pads the one that is operand 1's row
+    if (row_dim == 0) { *c0 = D0 > cols2_p ? D0 : cols2_p; *c1 = D1 > cols_p ? D1 : cols_p; }
+    else              { *c0 = D0 > cols_p ? D0 : cols_p;   *c1 = D1 > cols2_p ? D1 : cols2_p; }
+}
+extern "C" int uig_pack_tiles2(int D0, int D1, int kH, int kW, int row_dim, int cols_padded, int cols2_padded) {
+    const int taps = kH * kW;
+    if (taps > 64 || D0 <= 0 || D1 <= 0 || (row_dim != 0 && row_dim != 1)) return -1;
+    int c0, c1;
+    pack2_ranges(D0, D1, row_dim, cols_padded, cols2_padded, &c0, &c1);
+    return ((c0 + PK_TD0 - 1) / PK_TD0) * ((c1 + pack_td1(taps) - 1) / pack_td1(taps));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_multi2_kernel(const PackItem2* __restrict__ items, int nitems, long total) {
+    constexpr int E = ElemTraits<T>::E;
+    __shared__ float seg[PK_TD0][PK_MAXSEG + 1];
+    __shared__ int s_item;
+    const int tid = threadIdx.x;
+    for (long blk = blockIdx.x; blk < total; blk += gridDim.x) {
+        if (tid == 0) {
+            int lo = 0, hi = nitems - 1;                 // first item whose work_end > blk
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (items[mid].work_end > blk) hi = mid; else lo = mid + 1; }
+            s_item = lo;
+        }
+        __syncthreads();
+        const int ii = s_item;
+        const PackItem2 it = items[ii];
+        const long j = blk - (ii ? items[ii - 1].work_end : 0);
+        const int taps = it.taps, TD1 = pack_td1(taps);
+        int c0, c1;
+        pack2_ranges(it.D0, it.D1, it.row_dim, it.cols_p, it.cols2_p, &c0, &c1);
+        const int n1 = (c1 + TD1 - 1) / TD1;
+        const int d0b = (int)(j / n1) * PK_TD0, d1b = (int)(j % n1) * TD1;
+        const int nd1 = min(TD1, it.D1 - d1b);
+        const int len = max(nd1, 0) * taps;
+        for (int g = 0; g < PK_TD0; ++g) {
+            const bool rok = d0b + g < it.D0;
+            const float* src = it.w + ((long)(d0b + g) * it.D1 + d1b) * taps;
+            for (int i = tid; i < TD1 * taps; i += 256) seg[g][i] = (rok && i < len) ? src[i] : 0.f;
+        }
+        __syncthreads();
+        // operand with rows = d0 ([d0][tap][d1 chunk]) and operand with rows = d1 ([d1][tap][d0 chunk]); rows are never padded
+        T* dstA = static_cast<T*>(it.row_dim == 0 ? it.dst : it.dst2);
+        T* dstB = static_cast<T*>(it.row_dim == 0 ? it.dst2 : it.dst);
+        const int colsA = it.row_dim == 0 ? it.cols_p : it.cols2_p, colsB = it.row_dim == 0 ? it.cols2_p : it.cols_p;
+        {
+            const int cpt = TD1 / E;
+            for (int c = tid; c < PK_TD0 * taps * cpt; c += 256) {
+                const int k = c % cpt, tap = (c / cpt) % taps, g = c / (cpt * taps);
+                const int d0 = d0b + g, d1 = d1b + k * E;
+                if (d0 >= it.D0 || d1 >= colsA) continue;
+                float v[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[e] = seg[g][(k * E + e) * taps + tap];
+                *reinterpret_cast<u32x4_t*>(dstA + ((long)d0 * taps + tap) * colsA + d1) = f32_to_chunk<T>(v);
+            }
+        }
+        {
+            constexpr int CPG = PK_TD0 / E;
+            for (int c = tid; c < TD1 * taps * CPG; c += 256) {
+                const int k = c % CPG, tap = (c / CPG) % taps, i1 = c / (CPG * taps);
+                const int d1 = d1b + i1, d0 = d0b + k * E;
+                if (d1 >= it.D1 || d0 >= colsB) continue;
+                float v[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[e] = seg[k * E + e][i1 * taps + tap];
+                *reinterpret_cast<u32x4_t*>(dstB + ((long)d1 * taps + tap) * colsB + d0) = f32_to_chunk<T>(v);
+            }
+        }
+        __syncthreads();
+    }
+}
+extern "C" int uig_pack_weights_multi2(const void* items_dev, int nitems, int64_t total_work, int dtype, void* stream) {
+    UIG_CHECK_ARG(items_dev && nitems > 0 && total_work > 0, "uig_pack_weights_multi2: bad args");
+    const int g = (int)std::min<long>(total_work, 8192);
+    if (dtype == UIG_BF16) hipLaunchKernelGGL((pack_weights_multi2_kernel<bf16_t>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const PackItem2*)items_dev, nitems, (long)total_work);
+    else if (dtype == UIG_F32) hipLaunchKernelGGL((pack_weights_multi2_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const PackItem2*)items_dev, nitems, (long)total_work);
+    else return uig_set_error(-1, "uig_pack_weights_multi2: bad dtype %d", dtype);
+    UIG_LAUNCH_CHECK("uig_pack_weights_multi2");
+    return 0;
+}
+
 extern "C" int uig_pack_weights_multi(const void* items_dev, int nitems, int64_t total_work, int dtype, void* stream) {
     UIG_CHECK_ARG(items_dev && nitems > 0 && total_work > 0, "uig_pack_weights_multi: bad args");
     const int g = (int)std::min<long>(total_work, 8192);

@@ -83,6 +83,8 @@ SIGNATURES = {
     "uig_pack_weight": (_i, [_vp, _vp] + [_i] * 9 + [_vp]),
     "uig_pack_tiles": (_i, [_i] * 7),
     "uig_pack_weights_multi": (_i, [_vp, _i, _i64, _i, _vp]),
+    "uig_pack_tiles2": (_i, [_i] * 7),
+    "uig_pack_weights_multi2": (_i, [_vp, _i, _i64, _i, _vp]),
     "uig_instnorm_workspace_floats": (_sz, [_i, _i64, _i]),
     "uig_instnorm_act_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _i, _f, _i, _vp]),
     "uig_instnorm_act_fwd_pre": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _f, _i, _f, _i, _vp]),

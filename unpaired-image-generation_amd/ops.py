@@ -277,31 +277,29 @@ def pack_weights(spec: ConvSpec, weight: torch.Tensor, dtype: torch.dtype, wp_fw
 
 
 class MultiPacker:
-    """Packs every ConvLayer of a set of networks in ONE kernel launch (uig_pack_weights_multi).  The descriptor table holds
+    """Packs every ConvLayer of a set of networks in ONE kernel launch (uig_pack_weights_multi2: both operands of a layer from one read).  The descriptor table holds
     absolute device pointers, so it must be rebuilt if parameters or packed buffers are re-allocated (`valid()` checks)."""
 
     def __init__(self, layers):
         import numpy as np
         self.layers = list(layers)
-        dt = np.dtype([("w", "<u8"), ("dst", "<u8"), ("D0", "<i4"), ("D1", "<i4"), ("taps", "<i4"), ("row_dim", "<i4"),
-                       ("rows_p", "<i4"), ("cols_p", "<i4"), ("work_end", "<i8")])
-        assert dt.itemsize == 48
+        # one record per LAYER: both kernel-side operands come out of one pass over the fp32 weights (uig_pack_weights_multi2)
+        dt = np.dtype([("w", "<u8"), ("dst", "<u8"), ("dst2", "<u8"), ("D0", "<i4"), ("D1", "<i4"), ("taps", "<i4"), ("row_dim", "<i4"),
+                       ("cols_p", "<i4"), ("cols2_p", "<i4"), ("work_end", "<i8")])
+        assert dt.itemsize == 56
         recs, end = [], 0
         for l in self.layers:
             sp, w = l.spec, l.weight
             t = sp.k * sp.k
             D0, D1 = w.shape[0], w.shape[1]
-            if sp.kind == "conv":      # fwd rows = dim0 (Cout), dgrad rows = dim1 (Cin)
-                ops_ = ((l.wp_fwd, L.PACK_ROW_DIM0, sp.cout, sp.cin_p), (l.wp_dgrad, L.PACK_ROW_DIM1, sp.cin, sp.cout_p))
-            else:
-                ops_ = ((l.wp_fwd, L.PACK_ROW_DIM1, sp.cout, sp.cin_p), (l.wp_dgrad, L.PACK_ROW_DIM0, sp.cin, sp.cout_p))
-            for dst, rd, rows, cols in ops_:
-                assert dst.numel() == rows * t * cols
-                nt = int(L.lib().uig_pack_tiles(D0, D1, sp.k, sp.k, rd, rows, cols))
-                if nt <= 0:
-                    raise ValueError(f"uig_pack_tiles: unsupported weight shape {tuple(w.shape)}")
-                end += nt
-                recs.append((w.data_ptr(), dst.data_ptr(), D0, D1, t, rd, rows, cols, end))
+            # conv: fwd rows = dim0 (Cout), dgrad rows = dim1 (Cin); convT: the other way round
+            rd = L.PACK_ROW_DIM0 if sp.kind == "conv" else L.PACK_ROW_DIM1
+            assert l.wp_fwd.numel() == sp.cout * t * sp.cin_p and l.wp_dgrad.numel() == sp.cin * t * sp.cout_p
+            nt = int(L.lib().uig_pack_tiles2(D0, D1, sp.k, sp.k, rd, sp.cin_p, sp.cout_p))
+            if nt <= 0:
+                raise ValueError(f"uig_pack_tiles2: unsupported weight shape {tuple(w.shape)}")
+            end += nt
+            recs.append((w.data_ptr(), l.wp_fwd.data_ptr(), l.wp_dgrad.data_ptr(), D0, D1, t, rd, sp.cin_p, sp.cout_p, end))
         self.total = end
         self.ptrs = [(l.weight.data_ptr(), l.wp_fwd.data_ptr(), l.wp_dgrad.data_ptr()) for l in self.layers]
         arr = np.array(recs, dtype=dt)
@@ -330,7 +328,7 @@ class MultiPacker:
 
     def run(self):
         dt = L.BF16 if self.dtype == torch.bfloat16 else L.F32
-        L.check(L.lib().uig_pack_weights_multi(_p(self.items), self.n, self.total, dt, _stream()), "uig_pack_weights_multi")
+        L.check(L.lib().uig_pack_weights_multi2(_p(self.items), self.n, self.total, dt, _stream()), "uig_pack_weights_multi2")
         if self.qitems is not None:
             L.check(L.lib().uig_mx_quantize_multi(_p(self.qitems), self.qn, self.qblocks, _stream()), "uig_mx_quantize_multi")
         for l in self.layers:
