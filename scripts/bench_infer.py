@@ -20,8 +20,8 @@ g = u.Generator(n_blocks=9, dtype=torch.bfloat16)
 res = {}
 for rnd in range(3):
     for fused in (True, False):
-        ops.INFER_FUSED_IN = fused
-        for B, H, W in ((1, 256, 256), (1, 512, 512), (8, 256, 256)):
+        ops.INFER_FUSED_IN, ops.INFER_FUSED_MAX_BATCH = fused, 64
+        for B, H, W in ((1, 256, 256), (2, 256, 256), (4, 256, 256), (1, 512, 512), (8, 256, 256)):
             x = torch.rand(B, H, W, 8, device="cuda").to(torch.bfloat16)
             tr = Translator(g, use_graph=True)
             ms = ev_time(lambda: tr.run_phys(x))

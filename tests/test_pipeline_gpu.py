@@ -170,16 +170,16 @@ def test_inference_fused_instnorm_equals_training_kernels(dtype):
     g.load_state_dict(og.state_dict())
     for shape in ((1, 3, 256, 256), (3, 3, 64, 96)):
         x = torch.rand(*shape) * 2 - 1
-        old = ops.INFER_FUSED_IN
+        old, old_b = ops.INFER_FUSED_IN, ops.INFER_FUSED_MAX_BATCH
         try:
-            ops.INFER_FUSED_IN = True
+            ops.INFER_FUSED_IN, ops.INFER_FUSED_MAX_BATCH = True, 8          # (the default fuses batches <= 2 only)
             with torch.no_grad():
                 a = g(x.cuda())
             ops.INFER_FUSED_IN = False
             with torch.no_grad():
                 b = g(x.cuda())
         finally:
-            ops.INFER_FUSED_IN = old
+            ops.INFER_FUSED_IN, ops.INFER_FUSED_MAX_BATCH = old, old_b
         assert torch.equal(a, b), float((a - b).abs().max())
         with torch.no_grad():
             yref = og(x)

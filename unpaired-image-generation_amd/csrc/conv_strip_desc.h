@@ -84,7 +84,10 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
     const int l16 = lane & 15, q = lane >> 4;
     const bool vec_ok = ((d.Nstore & 3) == 0) && ((d.ldc & 3) == 0);
     const int nw0 = n_base + wn * WN;
-    if (MT == 4 && NT == 4 && vec_ok && nw0 + 64 <= d.Nstore && (d.ldc * (int)sizeof(T)) % 16 == 0) {      // wave-uniform choice
+    // 64 x 16 wave tiles (NT == 1: the 64 x 64-tile kernel of very small grids, round 3) take the plain full-row form only: the host
+    // never sends border / residual / norm-backward terms there
+    if (MT == 4 && (NT == 4 || (NT == 1 && d.border_add == nullptr && d.res_add == nullptr)) && vec_ok && nw0 + WN <= d.Nstore &&
+        (d.ldc * (int)sizeof(T)) % 16 == 0) {      // wave-uniform choice
         const int pw = p0 + wm * WM;
         T* ybase = y + (long)img * HoWo * d.ldc + nw0;
         float* so = nullptr;
@@ -93,7 +96,7 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
         auto rowp = [&](int r) -> T* { const int p = pw + r; return p < HoWo ? ybase + (long)p * d.ldc : nullptr; };
         if (d.border_add == nullptr && d.res_add == nullptr) {
             store_tile_via_lds<T, MT, NT>(acc, scratch, lane, nullptr, d.act, d.slope, rowp, so, min(64, HoWo - pw), NoRowAdd(), ehook);   // ehook: diagnostic stamp
-        } else {
+        } else if constexpr (NT == 4) {
             // reflection-pad dgrad: add the mirrored-border terms (phases T,B,L,R,TL,TR,BL,BR of the compact border buffer)
             constexpr int E = ElemTraits<T>::E;
             const int S = d.Ho;                                   // square map

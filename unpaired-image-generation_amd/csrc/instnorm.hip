@@ -201,6 +201,74 @@ __global__ __launch_bounds__(256) void in_apply_fwd_fin_kernel(const T* __restri
     }
 }
 
+// Round 3, channel-sliced form of the kernel above for small batches: a block owns 64 CHANNELS of a pixel range, so its finalize
+// prologue reads np * 64 * 8 bytes (32 KB at 64 partials) instead of np * C * 8 - at batch 1 the 23 finalize launches of a generator
+// call were 20 % of its latency (7.4 us each in the kernel trace) and the whole-C prologue cost more than it saved.  The 16
+// accumulators of a channel (the finalize kernel's 16 slab lanes) are spread over 4 threads (one load round), exchanged through LDS
+// and combined by the channel's thread in exactly in_finalize_kernel's order: bit-identical (mean, rstd).
+template <typename T>
+__global__ __launch_bounds__(256) void in_apply_fwd_fin_cs_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                                                  const float* __restrict__ partial, int np, double inv_n, float eps,
+                                                                  long HW, int C, int npx, int act, float slope) {
+    constexpr int E = ElemTraits<T>::E, CG = 64, CCG = CG / E, PLG = 256 / CCG;
+    __shared__ double acc_a[16][CG], acc_q[16][CG];
+    __shared__ float st[CG * 2];
+    const int tid = threadIdx.x, b = blockIdx.z, cg = blockIdx.y;
+    {
+        const int c = tid & (CG - 1), qd = tid >> 6;                 // channel of the group, quarter of its 16 accumulators
+        const float* pb = partial + ((long)b * np * C + cg * CG + c) * 2;
+        double a4[4] = {0.0, 0.0, 0.0, 0.0}, q4[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int s0 = 0; s0 < np; s0 += 16) {
+            u32x2_t v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const u32x2_t*>(pb + (long)min(s0 + 4 * qd + i, np - 1) * C * 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = s0 + 4 * qd + i < np;
+                a4[i] += ok ? (double)__uint_as_float(v[i][0]) : 0.0; q4[i] += ok ? (double)__uint_as_float(v[i][1]) : 0.0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc_a[4 * qd + i][c] = a4[i]; acc_q[4 * qd + i][c] = q4[i]; }
+    }
+    __syncthreads();
+    if (tid < CG) {
+        double a16[16], q16[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a16[i] = acc_a[i][tid]; q16[i] = acc_q[i][tid]; }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if ((i & o) == 0 && i < o) { a16[i] += a16[i ^ o]; q16[i] += q16[i ^ o]; }
+        const double mean = a16[0] * inv_n;
+        double var = q16[0] * inv_n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        st[2 * tid] = (float)mean; st[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int pl = tid / CCG, cc = tid % CCG;
+    const long sp = (HW + npx - 1) / npx;
+    const long p0 = blockIdx.x * sp, p1 = min(HW, p0 + sp);
+    const long base = (long)b * HW * C + cg * CG + cc * E;
+    float mu[E], rs[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { mu[e] = st[2 * (cc * E + e)]; rs[e] = st[2 * (cc * E + e) + 1]; }
+    for (long p = p0 + pl; p < p1; p += PLG) {
+        float v[E];
+        chunk_to_f32<T>(*reinterpret_cast<const u32x4_t*>(x + base + p * C), v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = apply_act((v[e] - mu[e]) * rs[e], act, slope);
+        if (res != nullptr) {
+            float r[E];
+            chunk_to_f32<T>(*reinterpret_cast<const u32x4_t*>(res + base + p * C), r);
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] += r[e];
+        }
+        *reinterpret_cast<u32x4_t*>(y + base + p * C) = f32_to_chunk<T>(v);
+    }
+}
+
 // COLSUM: additionally emit per-block partial sums of the written dx (as stored, i.e. after rounding to T) per channel:
 // the bias gradient of the convolution in front of this InstanceNorm is the column sum of exactly this tensor, so the
 // separate full read pass of uig_bias_grad disappears (it sat on the backward critical path).
@@ -418,6 +486,8 @@ extern "C" int uig_bias_grad(const void* dy, float* db, float* workspace, int64_
 
 // Inference forward (no statistics kept): partial != NULL -> the producing convolution's epilogue partials (np per image), ONE
 // launch; partial == NULL -> statistics pass into `workspace`, then the fused apply: two launches instead of three.
+static int g_infer_cs = 1;      // tuning / A-B hook: 0 = the whole-C form of the inference InstanceNorm (round 2)
+extern "C" void uig_debug_set_infer_cs(int on) { g_infer_cs = on; }
 extern "C" int uig_instnorm_act_fwd_infer(const void* x, const void* residual, void* y, const float* partial, int np, float* workspace,
                                           int B, int64_t HW, int C, float eps, int act, float slope, int dtype, void* stream) {
     UIG_CHECK_ARG(x && y && (partial || workspace), "uig_instnorm_act_fwd_infer: null pointer");
@@ -436,6 +506,16 @@ extern "C" int uig_instnorm_act_fwd_infer(const void* x, const void* residual, v
     UIG_CHECK_ARG(np > 0, "uig_instnorm_act_fwd_infer: np=%d", np);
     // blocks per image: every block pays the np * C * 8-byte finalize prologue (L2 reads).  Measured (scripts/bench_in_fin.py, 64x64x256,
     // MI355X): 4 pixels per thread (the training apply's shape) is best at batch 1, 8 at batch 8 and 16; 16 is worse everywhere
+    if (g_infer_cs && C % 64 == 0 && B <= 65535) {      // channel-sliced blocks: the finalize prologue reads 64 channels' partials only
+        const int E = dtype == UIG_BF16 ? 8 : 4, PLG = 256 / (64 / E);
+        const int npx = (int)std::max<long>(1, std::min<long>(4096, HW / (PLG * (B <= 2 ? 2 : 8))));
+        if (dtype == UIG_BF16)
+            hipLaunchKernelGGL((in_apply_fwd_fin_cs_kernel<bf16_t>), dim3(npx, C / 64, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, partial, np, 1.0 / (double)HW, eps, (long)HW, C, npx, act, slope);
+        else
+            hipLaunchKernelGGL((in_apply_fwd_fin_cs_kernel<float>), dim3(npx, C / 64, B), dim3(256), 0, s, (const float*)x, (const float*)residual, (float*)y, partial, np, 1.0 / (double)HW, eps, (long)HW, C, npx, act, slope);
+        UIG_LAUNCH_CHECK("uig_instnorm_act_fwd_infer(apply, channel-sliced)");
+        return 0;
+    }
     const int na = (int)std::max<long>(1, std::min<long>(2048, HW * CC / (256 * (B <= 2 ? 4 : 8))));
     if (dtype == UIG_BF16)
         hipLaunchKernelGGL((in_apply_fwd_fin_kernel<bf16_t>), dim3(na, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, partial, np, 1.0 / (double)HW, eps, (long)HW, C, CC, na, act, slope);

@@ -104,8 +104,8 @@ __device__ __forceinline__ void store_tile_via_lds(const f32x4_t (&acc)[NT][MT],
                                                    const float* bias4 /* NT*4 bias values of this lane, or nullptr */,
                                                    int act, float slope, RowPtr row_ptr, float* stat_out = nullptr,
                                                    int nvalid = 64, RowAdd row_add = RowAdd(), MidHook mid = MidHook()) {
-    static_assert(MT == 4 && NT == 4, "64 x 64 wave tile");
-    constexpr int ROWB = 64 * (int)sizeof(T);          // 128 (bf16) / 256 (f32) bytes per pixel row
+    static_assert(MT == 4 && (NT == 4 || NT == 2 || NT == 1) && NT * 16 * sizeof(T) >= 32, "64-pixel x 64- / 32- / 16-channel wave tile");
+    constexpr int ROWB = NT * 16 * (int)sizeof(T);     // bytes per pixel row of the wave tile: 128 (bf16) / 256 (f32) at 64 channels; 32 at 16 bf16 channels
     constexpr int NCH = ROWB / 16;                     // 16-byte chunks per row
     const int l16 = lane & 15, q = lane >> 4;
     // The activation is a launch constant: ONE branch around the whole conversion loop, not a switch per element.  With the switch

@@ -821,12 +821,12 @@ class PairConvFn(Function):
         return (*_conv_backward(ctx, dy, ctx.layers, ctx.group), None, None, None, None)
 
 
-# ----------------------------------------------------------------------------------------- instance norm (+act, +residual)
-# no-grad forwards: InstanceNorm finalised inside its apply kernel (SURVEY §8(f) row 4's "fused IN for latency").  OFF by default:
-# measured on MI355X (scripts/bench_infer.py, G9 bf16, batch 1, 256x256, HIP graph) 1.371 ms with the 19 ResBlock norms fused
-# against 0.959 ms with the finalize + apply launches - the per-block re-read and fp64 reduction of the partials (64 x 256
-# channels) costs ~25 us per norm, a finalize launch ~5 us.  Kept as an opt-in, bit-identical to the training kernels (tested).
-INFER_FUSED_IN = os.environ.get("UIG_INFER_FUSED_IN", "0") != "0"
+# Inference InstanceNorm (statistics finalised inside the apply launch, no finalize launch).  Round 2's form made every block
+# re-reduce ALL channels' partials (64 x 256 x 8 bytes): 1.371 vs 0.959 ms at batch 1 - opt-in then.  Round 3: blocks own 64 channels
+# and finalise only those (in_apply_fwd_fin_cs_kernel): G9 bf16 1 x 256 x 256 0.800 -> 0.746 ms, bit-identical; a tie at 512 x 512
+# (its ResBlock maps have 256 partials: not fused) and 1.5 % slower at batch 8 - so ON by default for batches <= 2 only.
+INFER_FUSED_IN = os.environ.get("UIG_INFER_FUSED_IN", "1") != "0"
+INFER_FUSED_MAX_BATCH = int(os.environ.get("UIG_INFER_FUSED_MAX_BATCH", "2"))
 
 
 def instnorm_infer(x, residual, act, slope, eps):
@@ -849,7 +849,8 @@ def instnorm_infer_applicable(x) -> bool:
     """every block of the fused kernel re-reads the image's partial statistics (np * C * 8 bytes): only worth it for the small
     maps of the ResBlocks (64 partials per image at 256x256), not for the 128^2 / 256^2 layers (256 / 1024 partials)"""
     pre = getattr(x, "_uig_in_partial", None)
-    return pre is not None and pre[1] <= INFER_FUSED_MAX_PARTIALS and pre[0].numel() == x.shape[0] * pre[1] * x.shape[3] * 2
+    return pre is not None and x.shape[0] <= INFER_FUSED_MAX_BATCH and pre[1] <= INFER_FUSED_MAX_PARTIALS and \
+        pre[0].numel() == x.shape[0] * pre[1] * x.shape[3] * 2
 
 
 class InstNormActFn(Function):
