@@ -20,13 +20,13 @@ g = u.Generator(n_blocks=9, dtype=torch.bfloat16)
 res = {}
 for rnd in range(3):
     for mode, name in ((2, "128x128 tiles"), (1, "64x64 tiles  ")):
-        lib.uig_debug_set_strip_small(mode)
+        u.ops.small_grid_kernels.MODE = mode         # what the Translator switches on around its launches
         for B, H, W in ((1, 256, 256), (2, 256, 256), (4, 256, 256), (1, 512, 512)):
             x = torch.rand(B, H, W, 8, device="cuda").to(torch.bfloat16)
             tr = Translator(g, use_graph=True)
             res.setdefault((B, H, name), []).append(ev_time(lambda: tr.run_phys(x)))
             del tr
-lib.uig_debug_set_strip_small(0)
+u.ops.small_grid_kernels.MODE = 0
 for (B, H, name), v in sorted(res.items()):
     v = sorted(v)
     print(f"G9 bf16 B={B} {H}x{H} {name}: median {v[len(v)//2]:7.3f} ms  min {v[0]:7.3f} ms")

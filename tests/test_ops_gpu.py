@@ -1167,7 +1167,7 @@ def test_strip64_small_grid_variant_equals_128_tile_kernel(S, cin, cout, B, grou
             torch.cuda.synchronize()
             outs[mode] = o
     finally:
-        lib.uig_debug_set_strip_small(0)
+        lib.uig_debug_set_strip_small(2)
     assert torch.equal(outs[2][0], outs[1][0]), "64 x 64-tile kernel output differs from the 128 x 128-tile kernel's"
     if pm == "zero":
         assert torch.equal(outs[2][-1], outs[1][-1]), "input gradient differs"

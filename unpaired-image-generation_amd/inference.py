@@ -48,7 +48,10 @@ class Translator:
 
     # ------------------------------------------------------------------------------------------------ physical path
     def _forward_phys(self, xp):
-        with torch.no_grad():
+        # small_grid_kernels: the 64x64-tile strip kernel for very small grids (batch 1).  Its fused statistics sum in another order than
+        # the other strip kernels' (1e-5), so a kernel choice that depends on the batch would make per-image results depend on the batch:
+        # the train step, whose data-parallel form must equal the full-batch step, never selects it; inference does (round 3)
+        with torch.no_grad(), ops.small_grid_kernels():
             return self.g.forward_phys(xp)
 
     def run_phys(self, xp: torch.Tensor) -> torch.Tensor:

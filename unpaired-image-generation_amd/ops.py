@@ -829,6 +829,22 @@ INFER_FUSED_IN = os.environ.get("UIG_INFER_FUSED_IN", "1") != "0"
 INFER_FUSED_MAX_BATCH = int(os.environ.get("UIG_INFER_FUSED_MAX_BATCH", "2"))
 
 
+class small_grid_kernels:
+    """Context manager (inference only): let plain 3x3 launches of very small grids (<= 64 blocks of 128x128: batch 1) run on the
+    64x64-tile strip kernel while it is active (kernel selection is process-global library state: not for concurrent use from several
+    threads).  Captured HIP graphs keep the choice made at capture time."""
+
+    MODE = int(os.environ.get("UIG_INFER_SMALL_GRID", "0"))      # 0 = auto (default), 1 = wherever it applies, 2 = never (A/B)
+
+    def __enter__(self):
+        L.lib().uig_debug_set_strip_small(self.MODE)
+        return self
+
+    def __exit__(self, *exc):
+        L.lib().uig_debug_set_strip_small(2)
+        return False
+
+
 def instnorm_infer(x, residual, act, slope, eps):
     """InstanceNorm(+act, +residual) forward with no autograd state (inference): the statistics are
     finalised inside the apply kernel - one launch behind a convolution that emitted the partials, two otherwise."""
