@@ -60,6 +60,7 @@ void uig_debug_set_mirror(int on);
 void uig_debug_set_rowstrip(int on);
 void uig_debug_set_infer_cs(int on);              /* inference InstanceNorm (uig_instnorm_act_fwd_infer): 1 (default) = blocks own 64 channels and finalise only those, 0 = round 2's whole-C form */
 void uig_debug_set_strip_small(int mode);         /* 64x64-tile bf16 strip kernel (four waves of 64 px x 16 ch) for plain launches: 2 = never (default: training keeps a batch-independent kernel choice), 0 = auto (grids of <= 64 128x128 blocks; the inference path switches it on around its launches), 1 = wherever it applies */
+void uig_debug_set_strip_small_stages(int n);     /* weight stages of the 64x64-tile kernel: 4 (default: tiles three K-steps ahead, counted waits) / 2 */
 void uig_debug_set_strip_stages(int n);           /* 128x128-tile bf16 strip kernel: weight stages 2 (default) / 4 (three K-steps ahead, counted waits: measured slower, A-B hook) */
 /* diagnostic build hook: device buffer (u64[blocks*8*4]) that receives in-kernel cycle stamps; NULL = off (default) */
 void uig_debug_set_strip_stamps(void* dev_buf);

@@ -1168,6 +1168,15 @@ def test_strip64_small_grid_variant_equals_128_tile_kernel(S, cin, cout, B, grou
             outs[mode] = o
     finally:
         lib.uig_debug_set_strip_small(2)
+    # the same kernel with two weight stages instead of its default four (tiles three K-steps ahead, counted waits): bit-identical,
+    # statistics included
+    try:
+        lib.uig_debug_set_strip_small(1); lib.uig_debug_set_strip_small_stages(2)
+        y2 = ops.conv_forward(ls[0].spec, x, ls[0].wp_fwd, ls[0].bias, pair=fpair, want_in_stats=want_stats)
+        torch.cuda.synchronize()
+        assert torch.equal(y2, outs[1][0]) and (not want_stats or torch.equal(y2._uig_in_partial[0], outs[1][1]))
+    finally:
+        lib.uig_debug_set_strip_small(2); lib.uig_debug_set_strip_small_stages(4)
     assert torch.equal(outs[2][0], outs[1][0]), "64 x 64-tile kernel output differs from the 128 x 128-tile kernel's"
     if pm == "zero":
         assert torch.equal(outs[2][-1], outs[1][-1]), "input gradient differs"

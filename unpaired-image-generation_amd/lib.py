@@ -32,6 +32,7 @@ SIGNATURES = {
     "uig_debug_set_rowstrip": (None, [_i]),
     "uig_debug_set_strip_stages": (None, [_i]),
     "uig_debug_set_strip_small": (None, [_i]),
+    "uig_debug_set_strip_small_stages": (None, [_i]),
     "uig_debug_set_infer_cs": (None, [_i]),
     "uig_debug_set_strip_stamps": (None, [_vp]),
     "uig_debug_set_mx_stamps": (None, [_vp]),
