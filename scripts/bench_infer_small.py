@@ -19,9 +19,9 @@ def ev_time(fn, iters=100):
 g = u.Generator(n_blocks=9, dtype=torch.bfloat16)
 res = {}
 for rnd in range(3):
-    for mode, name in ((2, "128x128 tiles"), (1, "64x64 tiles  ")):
+    for mode, name in ((2, "128x128 tiles (4 waves)       "), (0, "auto: 64x64 / 128x64 by grid   "), (3, "128x64 tiles wherever it applies")):
         u.ops.small_grid_kernels.MODE = mode         # what the Translator switches on around its launches
-        for B, H, W in ((1, 256, 256), (2, 256, 256), (4, 256, 256), (1, 512, 512)):
+        for B, H, W in ((1, 256, 256), (2, 256, 256), (3, 256, 256), (4, 256, 256), (1, 512, 512)):
             x = torch.rand(B, H, W, 8, device="cuda").to(torch.bfloat16)
             tr = Translator(g, use_graph=True)
             res.setdefault((B, H, name), []).append(ev_time(lambda: tr.run_phys(x)))

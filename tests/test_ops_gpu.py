@@ -1177,6 +1177,16 @@ def test_strip64_small_grid_variant_equals_128_tile_kernel(S, cin, cout, B, grou
         assert torch.equal(y2, outs[1][0]) and (not want_stats or torch.equal(y2._uig_in_partial[0], outs[1][1]))
     finally:
         lib.uig_debug_set_strip_small(2); lib.uig_debug_set_strip_small_stages(4)
+    # the 128 x 64-tile form (eight waves of 64 pixels x 16 channels; grids of 65 .. 128 blocks: batch-2 inference): same epilogue, same K order
+    try:
+        lib.uig_debug_set_strip_small(3)
+        y3 = ops.conv_forward(ls[0].spec, x, ls[0].wp_fwd, ls[0].bias, pair=fpair, want_in_stats=want_stats)
+        torch.cuda.synchronize()
+        assert torch.equal(y3, outs[2][0])
+        if want_stats:
+            assert float((y3._uig_in_partial[0] - outs[2][1]).abs().max()) <= 1e-5 * float(outs[2][1].abs().max())
+    finally:
+        lib.uig_debug_set_strip_small(2)
     assert torch.equal(outs[2][0], outs[1][0]), "64 x 64-tile kernel output differs from the 128 x 128-tile kernel's"
     if pm == "zero":
         assert torch.equal(outs[2][-1], outs[1][-1]), "input gradient differs"
