@@ -2,7 +2,9 @@
 """bench.py — images/sec of the full CycleGAN train step (3x256x256) on N MI355X, one process per GPU.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-  N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+  N>1: either  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+       or plain  python bench.py --gpus N ...  : without WORLD_SIZE in the environment the process starts that launcher itself as a
+       CHILD (before torch is imported or the GPU touched: no exec of a GPU process) and exits with its status.
 
 One "step" = one full optimisation step on a per-GPU batch of `--batch` (default 4: BASELINE.json
 configs[1]) synthetic (real_A, real_B) pairs; value = global pairs / second (weak scaling).  Rank 0 prints ONE JSON line
@@ -71,6 +73,41 @@ def step_time_floor(flops, size, dtype):
     return flops * share8 / PEAK_FP8 + flops * (1.0 - share8) / PEAK_BF16
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: start torch.distributed.run (one rank per GPU, rendezvous on
+    127.0.0.1, a free port) as a child process with this script and the same arguments, and return its exit status.  The parent
+    has not imported torch and never touches the GPU; the ranks are fresh processes."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_launch():
+    """--dry-launch: the launch plumbing alone, no GPU - every rank joins a gloo group, the ranks are counted with an all-reduce
+    and rank 0 prints ONE line (tests/test_dp_cpu.py runs this with --gpus 2 in the CPU container)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen = 1
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "world": world, "ranks_seen": seen, "local_rank": int(os.environ.get("LOCAL_RANK", "0"))}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,7 +125,13 @@ def main():
                     help="BASELINE.json configs[k-1] as a preset: 1 = G6@64 forward parity smoke (no timing), 2 = the headline (256^2, batch 4, bf16), "
                          "3 = config 2 per GPU on --gpus ranks (batch 32 over 8), 4 = 512^2 batch 2 per GPU, 5 = 256^2 batch 8 per GPU, MX fp8 ResBlock convs")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short timings of configs[3] / configs[4] appended to the default line")
+    ap.add_argument("--dry-launch", action="store_true", help="exercise the rank launch only (gloo, no GPU): rank 0 prints one line")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))       # nothing below has run: torch is not imported, the GPU is untouched
+    if args.dry_launch:
+        assert int(os.environ.get("WORLD_SIZE", "1")) == args.gpus, "WORLD_SIZE does not match --gpus"
+        return dry_launch()
     if args.config is not None:
         if args.config == 1:
             import __graft_entry__

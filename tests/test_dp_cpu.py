@@ -185,3 +185,19 @@ def test_param_views_follow_the_interleaved_layout():
     grp.m.copy_(torch.arange(grp.m.numel(), dtype=torch.float32))
     mv = grp.param_views(grp.m)
     assert float(mv[1].reshape(-1)[0]) == grp._starts[1]
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver invokes the multi-GPU bench) must start its own ranks:
+    the parent spawns torch.distributed.run as a child before touching torch / the GPU.  --dry-launch keeps the ranks on gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j == {"dry_launch": True, "world": 2, "ranks_seen": 2, "local_rank": 0}

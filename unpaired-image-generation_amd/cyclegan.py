@@ -195,10 +195,15 @@ class CycleGAN:
             if taps:
                 # pass 1 (the 4B-image pass) is the LAST part of the backward pass and a chain through its ResBlocks: cut there
                 cuts = [taps[i] for i in self.cuts_G]
+                n_st = len(cuts) + 1
                 for k in staged_backward(losses, cuts, self._stage_params((self.G_A, self.G_B), self.cuts_G), ctx):
-                    if last is not None:
-                        yield last
-                    last = k
+                    # stages 0 .. n-2 are yielded the moment they finish (their buckets lie behind a cut of pass 1: every layer pair in
+                    # them has been visited by both passes, nothing is left in the stash for them) so that bucket k's all-reduce runs
+                    # under stage k+1; only the final index waits for the region's exit flush
+                    if k < n_st - 1:
+                        yield k
+                    else:
+                        last = k
             else:
                 with ctx(0) if ctx else contextlib.nullcontext():
                     ops.backward_unit(losses)
