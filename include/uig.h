@@ -121,6 +121,22 @@ int uig_conv_gather_bst(const void* x, const void* wp, const float* bias, const 
                         int act, float slope, int dtype,
                         const void* bst_x, const float* bst_stats, int bst_act, float bst_slope, float* bst_partial, void* stream);
 
+/* Round 4 - statistics that come out of the convolution launch FINAL (no finalize launch between a convolution and the InstanceNorm
+ * apply pass behind it).  uig_conv_gather_ex plus: in_stats fp32[B][Nstore][2] receives (mean, rstd) with eps = in_eps, bit-identical
+ * to uig_instnorm_finalize(in_partial): the blocks of the launch take one ARRIVAL TICKET per tile and image after their statistics
+ * slabs are out (write-through stores, drained, one relaxed agent-scope fetch_add per block) and the block that draws an image's
+ * last ticket reduces that image's slabs in the finalize kernel's fixed order.  tickets: >= B zero-initialised 32-bit words owned
+ * by the caller, left zero by the launch (one arena per device and stream of launches is enough: launches are stream-ordered).
+ * Kernel families without the in-launch form (and tickets == NULL) run the finalize launch behind the convolution: same result.
+ * uig_debug_set_in_tickets(0) forces that everywhere (A/B and parity hook).  Consumer: uig_instnorm_apply_fwd. */
+void uig_debug_set_in_tickets(int on);
+void uig_debug_set_colsum_slabs(int n);         /* tuning hook: pixel slabs per image of uig_instnorm_act_bwd_colsum* (default 32) */
+int uig_conv_gather_fin(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2,
+                        int group_images, float* in_partial, const void* border_add, const void* res_add, void* y,
+                        int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
+                        int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
+                        int act, float slope, int dtype, float* in_stats, float in_eps, unsigned* tickets, void* stream);
+
 /* Input gradient of a reflection-padded (pad 1) 3x3 stride-1 conv WITHOUT the padded (H+2)x(W+2) gradient + fold:
  * this computes the mirrored-border terms (8 groups: top/bottom/left/right lines + 4 corners) into bord[B][8][H][ldc];
  * then uig_conv_gather_ex(dy, ..., transposed, pad=1, zero, border_add=bord) produces dx on the exact HxW grid. */
@@ -133,10 +149,19 @@ int uig_conv_strip_applicable(int B, int H, int W, int Cin, int Nrows, int Ho, i
  * would have read a mirrored line or column; bf16, 64-pixel-wide maps of >= 8 lines, C % 64 == 0, Nrows == ldc, Nrows % 128 == 0):
  * dx (B, H, W, ldc) = zero-padded transposed conv of dy (B, H, W, C) + mirrored terms [+ res_add of dx's shape].  No border
  * buffer, no border GEMM in front.  uig_reflect3x3_dgrad_mirror_applicable: 1 where it applies, else use the two launches above
- * (which also carry the optional fused norm-backward statistics of uig_conv_gather_bst; this launch does not). */
+ * (which also carry the optional fused norm-backward statistics of uig_conv_gather_bst; uig_reflect3x3_dgrad_mirror_bst below is this launch with them). */
 int uig_reflect3x3_dgrad_mirror_applicable(int B, int H, int W, int C, int Nrows, int ldc, int dtype);
 int uig_reflect3x3_dgrad_mirror(const void* dy, const void* wp, const void* wp2, int group_images, const void* res_add, void* dx,
                                 int B, int H, int W, int C, int Nrows, int ldc, int dtype, void* stream);
+/* Round 4: the same launch (a variant of the mirror-pixel kernel) ALSO emits the statistics of the InstanceNorm backward that consumes
+ * dx as its dy - the arguments of uig_conv_gather_bst - and delivers them FINAL: bst_gm fp32[B][ldc][2] = (mean g, mean g*xhat),
+ * finalised inside the launch through `tickets` (>= B zero words, left zero; see uig_conv_gather_fin) or, with tickets == NULL, by
+ * a finalize launch behind it.  uig_instnorm_act_bwd_colsum_t(pre_gm = bst_gm) is then ONE launch: neither the norm's statistics
+ * pass (a full read of dy and x) nor a finalize launch.  dx is bitwise what uig_reflect3x3_dgrad_mirror writes. */
+int uig_reflect3x3_dgrad_mirror_bst(const void* dy, const void* wp, const void* wp2, int group_images, const void* res_add, void* dx,
+                                    int B, int H, int W, int C, int Nrows, int ldc, int dtype,
+                                    const void* bst_x, const float* bst_stats, int bst_act, float bst_slope, float* bst_partial, float* bst_gm,
+                                    unsigned* tickets, void* stream);
 
 /* ---- 3x3 stride-1 pad-1 convolution (zero or reflection padding) that applies the InstanceNorm(+ReLU / LeakyReLU) IN FRONT of
  * it to its own input as it is staged (round 3; replaces aten::instance_norm's apply pass + aten::convolution of a ResBlock's
@@ -301,6 +326,14 @@ int uig_instnorm_act_fwd_pre(const void* x, const void* residual, void* y, float
  * uig_instnorm_act_fwd[_pre] (same fp64 association order). */
 int uig_instnorm_act_fwd_infer(const void* x, const void* residual, void* y, const float* partial, int np, float* workspace,
                                int B, int64_t HW, int C, float eps, int act, float slope, int dtype, void* stream);
+/* Round 4 (see uig_conv_gather_fin): the forward apply pass alone on FINAL statistics (stats fp32[B][C][2] = (mean, rstd));
+ * mx_q / mx_s optional (both or none; bf16, C % 32 == 0: as uig_instnorm_act_fwd_mx). */
+int uig_instnorm_apply_fwd(const void* x, const void* residual, void* y, const float* stats, void* mx_q, void* mx_s,
+                           int B, int64_t HW, int C, int act, float slope, int dtype, void* stream);
+/* uig_instnorm_act_fwd whose statistics pass finalises itself through arrival tickets (>= B zero words, left zero): two launches
+ * instead of three, bit-identical.  mx_q / mx_s optional. */
+int uig_instnorm_act_fwd_t(const void* x, const void* residual, void* y, float* stats, float* workspace, unsigned* tickets,
+                           void* mx_q, void* mx_s, int B, int64_t HW, int C, float eps, int act, float slope, int dtype, void* stream);
 /* aten::native_batch_norm_backward (on the (1,B*C,H,W) view) fused with the activation's backward:
  *   g = dy * act'(xhat);  dx = rstd * (g - mean(g) - xhat * mean(g*xhat))                                   */
 int uig_instnorm_act_bwd(const void* dy, const void* x, const float* stats, void* dx, float* workspace,
@@ -317,6 +350,15 @@ int uig_instnorm_act_bwd_colsum_pre(const void* dy, const void* x, const float* 
                                     int B, int64_t HW, int C, int act, float slope, int dtype, void* stream);
 int uig_instnorm_act_bwd_colsum(const void* dy, const void* x, const float* stats, void* dx, float* workspace,
                                 float* colsum_partial, int B, int64_t HW, int C, int act, float slope, int dtype, void* stream);
+/* Round 4, the general form.  Where (mean g, mean g*xhat) come from: pre_gm != NULL - fp32[B][C][2], already final (finalised inside
+ * the launch that wrote dy: uig_reflect3x3_dgrad_mirror_bst): the apply launch alone; else pre_partial != NULL - that launch's epilogue
+ * partials (pre_nslab per image): finalize launch + apply (= uig_instnorm_act_bwd_colsum_pre); else this norm's own statistics pass,
+ * which finalises itself through `tickets` (>= B zero words, left zero): two launches instead of three.  Bit-identical to the forms
+ * above.  mx_q / mx_s optional (as uig_instnorm_act_bwd_colsum_mx). */
+int uig_instnorm_act_bwd_colsum_t(const void* dy, const void* x, const float* stats, void* dx, float* workspace,
+                                  float* colsum_partial, const float* pre_partial, int pre_nslab, const float* pre_gm,
+                                  unsigned* tickets, void* mx_q, void* mx_s,
+                                  int B, int64_t HW, int C, int act, float slope, int dtype, void* stream);
 int uig_bias_grad_from_partials(const float* colsum_partial, float* db, int nslab_total, int C, int Nreal,
                                 int accumulate, void* stream);
 

@@ -16,7 +16,6 @@
 #include "uig_common.h"
 #include <algorithm>
 
-struct UigBst { const void* x; const float* stats; float* partial; int act; float slope; };     // as in conv_strip_desc.h
 
 struct GatherDesc {
     int B, H, W, Cin;
@@ -406,7 +405,9 @@ static int dispatch_igemm(const void* x, const void* wp, const float* bias, void
 int uig_try_conv_strip(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
                        float* in_partial, const void* border_add, const void* res_add, void* y, int B, int H, int W, int Cin, int Nrows,
                        int k, int pad_mode, const int* taps, int ntaps, int dh_min, int dh_max, int Ho, int Wo, int ldc, int Nstore,
-                       int act, float slope, int dtype, long x_bytes, long w_bytes, hipStream_t s, int* rc_out, const UigBst* bst, int mirror);
+                       int act, float slope, int dtype, long x_bytes, long w_bytes, hipStream_t s, int* rc_out, UigBst* bst, int mirror, UigFinReq* fin);
+extern "C" int uig_instnorm_finalize(const float* partial, int nslab, float* stats, int B, int64_t HW, int C, float eps, void* stream);
+int uig_instnorm_finalize_bwd(const float* partial, int nslab, float* gm, int B, int64_t HW, int C, void* stream);      // instnorm.hip
 
 int uig_try_conv_cin8(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
                       void* y, int B, int H, int W, int Cin, int Nrows, int pad_mode, const int* taps, int ntaps,
@@ -426,10 +427,35 @@ int uig_try_conv_tr2(const void* x, const void* wp, const float* bias, const voi
 
 static int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
+static int conv_gather_impl2(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
+                             float* in_partial, const void* border_add, const void* res_add, void* y, int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
+                             int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
+                             int act, float slope, int dtype, void* stream, UigBst* bst, int mirror, UigFinReq* fin);
+
+// fin / bst->gm (round 4): the launch's statistics are wanted FINAL.  The kernel family that can finalises them inside its launch
+// (arrival tickets) and says so in `done`; for the rest the finalize launch runs here, behind the convolution - same bits either way.
 static int conv_gather_impl(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
                             float* in_partial, const void* border_add, const void* res_add, void* y, int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
                             int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
-                            int act, float slope, int dtype, void* stream, const UigBst* bst = nullptr, int mirror = 0) {
+                            int act, float slope, int dtype, void* stream, UigBst* bst = nullptr, int mirror = 0, UigFinReq* fin = nullptr) {
+    if (fin != nullptr) { UIG_CHECK_ARG(in_partial && fin->stats, "uig_conv_gather_fin: in_partial and in_stats go together"); fin->done = 0; }
+    if (bst != nullptr) bst->done = 0;
+    int rc = conv_gather_impl2(x, wp, bias, wp2, bias2, group_images, in_partial, border_add, res_add, y, B, H, W, Cin, Nrows, kH, kW, stride, pad,
+                               pad_mode, gather_mode, Ho, Wo, ldc, Nstore, act, slope, dtype, stream, bst, mirror, fin);
+    if (rc) return rc;
+    if (fin != nullptr && !fin->done) {
+        rc = uig_instnorm_finalize(in_partial, Ho * Wo / 64, fin->stats, B, (int64_t)Ho * Wo, Nstore, fin->eps, stream);
+        if (rc) return rc;
+    }
+    if (bst != nullptr && bst->gm != nullptr && !bst->done)
+        rc = uig_instnorm_finalize_bwd(bst->partial, Ho * Wo / 64, bst->gm, B, (int64_t)Ho * Wo, Nstore, stream);
+    return rc;
+}
+
+static int conv_gather_impl2(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2, int group_images,
+                             float* in_partial, const void* border_add, const void* res_add, void* y, int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
+                             int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
+                             int act, float slope, int dtype, void* stream, UigBst* bst, int mirror, UigFinReq* fin) {
     UIG_CHECK_ARG(x && wp && y, "uig_conv_gather: null pointer");
     if (wp2 != nullptr) UIG_CHECK_ARG(group_images > 0 && group_images < B, "uig_conv_gather_pair: group_images=%d must be in (0, B=%d)", group_images, B);
     UIG_CHECK_ARG(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "uig_conv_gather: bad shape B=%d H=%d W=%d Ho=%d Wo=%d", B, H, W, Ho, Wo);
@@ -523,7 +549,7 @@ static int conv_gather_impl(const void* x, const void* wp, const float* bias, co
         int dmin = 127, dmax = -127, rc = 0;
         for (int t = 0; t < kH * kW; ++t) { const int dh = (d.tap[t] & 255) - 128; dmin = std::min(dmin, dh); dmax = std::max(dmax, dh); }
         if (uig_try_conv_strip(x, wp, bias, wp2, bias2, group_images, in_partial, border_add, res_add, y, B, H, W, Cin, Nrows, kH, pad_mode, d.tap, kH * kW, dmin, dmax,
-                               Ho, Wo, ldc, Nstore, act, slope, dtype, (long)d.x_bytes, (long)d.w_bytes, s, &rc, bst, mirror))
+                               Ho, Wo, ldc, Nstore, act, slope, dtype, (long)d.x_bytes, (long)d.w_bytes, s, &rc, bst, mirror, fin))
             return rc;
     }
     UIG_CHECK_ARG(mirror == 0, "uig_reflect3x3_dgrad_mirror: shape not taken by the persistent strip kernel (query uig_reflect3x3_dgrad_mirror_applicable)");
@@ -534,12 +560,12 @@ static int conv_gather_impl(const void* x, const void* wp, const float* bias, co
         if (grows % 256 != 0 && in_partial != nullptr) {      // fused-statistics slabs assume 64-row alignment of both groups: two launches (same results)
             const long esz2 = dtype == UIG_BF16 ? 2 : 4;
             const long pstride = (long)(Ho * Wo / 64) * Nstore * 2;
-            int rc = conv_gather_impl(x, wp, bias, nullptr, nullptr, 0, in_partial, nullptr, nullptr, y, group_images, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode,
-                                      gather_mode, Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
+            int rc = conv_gather_impl2(x, wp, bias, nullptr, nullptr, 0, in_partial, nullptr, nullptr, y, group_images, H, W, Cin, Nrows, kH, kW, stride, pad, pad_mode,
+                                       gather_mode, Ho, Wo, ldc, Nstore, act, slope, dtype, stream, nullptr, 0, nullptr);
             if (rc) return rc;
-            return conv_gather_impl((const char*)x + (long)group_images * H * W * Cin * esz2, wp2, bias2, nullptr, nullptr, 0,
-                                    in_partial ? in_partial + group_images * pstride : nullptr, nullptr, nullptr, (char*)y + (long)group_images * Ho * Wo * ldc * esz2, B - group_images, H, W, Cin, Nrows, kH, kW,
-                                    stride, pad, pad_mode, gather_mode, Ho, Wo, ldc, Nstore, act, slope, dtype, stream);
+            return conv_gather_impl2((const char*)x + (long)group_images * H * W * Cin * esz2, wp2, bias2, nullptr, nullptr, 0,
+                                     in_partial ? in_partial + group_images * pstride : nullptr, nullptr, nullptr, (char*)y + (long)group_images * Ho * Wo * ldc * esz2, B - group_images, H, W, Cin, Nrows, kH, kW,
+                                     stride, pad, pad_mode, gather_mode, Ho, Wo, ldc, Nstore, act, slope, dtype, stream, nullptr, 0, nullptr);
         }
         d.wp2 = wp2; d.bias2 = bias2; d.group_rows = (int)grows;
     }
@@ -584,9 +610,24 @@ extern "C" int uig_conv_gather_bst(const void* x, const void* wp, const float* b
                                    int act, float slope, int dtype,
                                    const void* bst_x, const float* bst_stats, int bst_act, float bst_slope, float* bst_partial, void* stream) {
     UIG_CHECK_ARG(bst_x && bst_stats && bst_partial, "uig_conv_gather_bst: null statistics pointer");
-    const UigBst b{bst_x, bst_stats, bst_partial, bst_act, bst_slope};
+    UigBst b{bst_x, bst_stats, bst_partial, bst_act, bst_slope, nullptr, nullptr, 0};
     return conv_gather_impl(x, wp, bias, wp2, bias2, wp2 ? group_images : 0, in_partial, border_add, res_add, y, B, H, W, Cin, Nrows, kH, kW, stride, pad,
                             pad_mode, gather_mode, Ho, Wo, ldc, Nstore, act, slope, dtype, stream, &b);
+}
+
+// uig_conv_gather_ex whose fused InstanceNorm statistics come out FINAL (round 4): in_stats fp32[B][Nstore][2] = (mean, rstd) with
+// eps = in_eps, bit-identical to uig_instnorm_finalize on in_partial.  Where the kernel family supports it the image's last-arriving
+// block finalises inside the convolution launch (arrival tickets: `tickets` = >= B zero-initialised 32-bit words, left zero); elsewhere
+// the finalize launch runs behind the convolution.  tickets == NULL: always the latter.
+extern "C" int uig_conv_gather_fin(const void* x, const void* wp, const float* bias, const void* wp2, const float* bias2,
+                                   int group_images, float* in_partial, const void* border_add, const void* res_add, void* y,
+                                   int B, int H, int W, int Cin, int Nrows, int kH, int kW, int stride, int pad,
+                                   int pad_mode, int gather_mode, int Ho, int Wo, int ldc, int Nstore,
+                                   int act, float slope, int dtype, float* in_stats, float in_eps, unsigned* tickets, void* stream) {
+    UIG_CHECK_ARG(in_partial && in_stats, "uig_conv_gather_fin: null statistics pointer");
+    UigFinReq f{in_stats, in_eps, tickets, 0};
+    return conv_gather_impl(x, wp, bias, wp2, bias2, wp2 ? group_images : 0, in_partial, border_add, res_add, y, B, H, W, Cin, Nrows, kH, kW, stride, pad,
+                            pad_mode, gather_mode, Ho, Wo, ldc, Nstore, act, slope, dtype, stream, nullptr, 0, &f);
 }
 
 // Input gradient of a reflection-padded (pad 1) 3x3 stride-1 convolution in ONE launch: dx (B, H, W, ldc) = the zero-padded
@@ -598,6 +639,19 @@ extern "C" int uig_reflect3x3_dgrad_mirror(const void* dy, const void* wp, const
     UIG_CHECK_ARG(dy && wp && dx, "uig_reflect3x3_dgrad_mirror: null pointer");
     return conv_gather_impl(dy, wp, nullptr, wp2, nullptr, wp2 ? group_images : 0, nullptr, nullptr, res_add, dx, B, H, W, C, Nrows, 3, 3, 1, 1, UIG_PAD_ZERO,
                             UIG_GATHER_TRANSPOSED, H, W, ldc, ldc, UIG_ACT_NONE, 0.f, dtype, stream, nullptr, 1);
+}
+
+// uig_reflect3x3_dgrad_mirror that also produces the statistics of the InstanceNorm BACKWARD consuming dx as its dy (round 4; the
+// arguments of uig_conv_gather_bst): bst_partial fp32[B][H*W/64][ldc][2] and, finalised (inside the launch through `tickets`, or by a
+// finalize launch behind it when tickets == NULL), bst_gm fp32[B][ldc][2] = (mean g, mean g*xhat) for uig_instnorm_act_bwd_colsum_t.
+extern "C" int uig_reflect3x3_dgrad_mirror_bst(const void* dy, const void* wp, const void* wp2, int group_images, const void* res_add, void* dx,
+                                               int B, int H, int W, int C, int Nrows, int ldc, int dtype,
+                                               const void* bst_x, const float* bst_stats, int bst_act, float bst_slope, float* bst_partial, float* bst_gm,
+                                               unsigned* tickets, void* stream) {
+    UIG_CHECK_ARG(dy && wp && dx && bst_x && bst_stats && bst_partial && bst_gm, "uig_reflect3x3_dgrad_mirror_bst: null pointer");
+    UigBst b{bst_x, bst_stats, bst_partial, bst_act, bst_slope, bst_gm, tickets, 0};
+    return conv_gather_impl(dy, wp, nullptr, wp2, nullptr, wp2 ? group_images : 0, nullptr, nullptr, res_add, dx, B, H, W, C, Nrows, 3, 3, 1, 1, UIG_PAD_ZERO,
+                            UIG_GATHER_TRANSPOSED, H, W, ldc, ldc, UIG_ACT_NONE, 0.f, dtype, stream, &b, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -39,9 +39,11 @@ struct StripDesc {
     int nrm_act; float nrm_slope;
     void* nrm_h;
     int wide512;             // persistent bf16 kernel: 1 = the 512-row strip without zero rows (conv_strip_pk.hip, NOZ; set by uig_try_conv_strip)
+    // round 4, persistent kernel: in-launch finalize (arrival tickets, uig_common.h) of the forward statistics (fin: in_partial -> (mean, rstd))
+    // and of the norm-backward statistics (bfin: bst_partial -> (mean g, mean g*xhat)); tickets == NULL = off (the caller runs the finalize launch)
+    UigFin fin, bfin;
 };
 
-struct UigBst { const void* x; const float* stats; float* partial; int act; float slope; };
 
 template <typename T> struct MmaS;
 template <> struct MmaS<bf16_t> {
@@ -77,7 +79,8 @@ __device__ __forceinline__ void strip_init_acc(f32x4_t (&acc)[NT][MT], const flo
 // residual adds, optional InstanceNorm partial statistics; full-row stores through this wave's 64x64 LDS scratch when its 64
 // channels are all stored, else direct 8/16-byte stores.  The bias is already in the accumulators (strip_init_acc).
 // The caller has made sure (barrier) that `scratch` is free.
-template <typename T, int MT, int NT, int WM, int WN, bool BORD = true, typename EHook = NoMidHook>
+// BSTE: compile the norm-backward statistics (d.bst_*) in - always with the border form (BORD), an opt-in variant of the mirror-pixel kernel
+template <typename T, int MT, int NT, int WM, int WN, bool BORD = true, typename EHook = NoMidHook, bool BSTE = BORD>
 __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], unsigned char* scratch, const StripDesc& d, T* __restrict__ y,
                                                int img, int p0, int wm, int wn, int n_base, int lane, EHook ehook = EHook()) {
     const int HoWo = d.Ho * d.Wo;
@@ -94,8 +97,8 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
         if (d.in_partial != nullptr && pw < HoWo)
             so = d.in_partial + (((long)img * ((HoWo + 63) / 64) + pw / 64) * d.Nstore + nw0) * 2;
         auto rowp = [&](int r) -> T* { const int p = pw + r; return p < HoWo ? ybase + (long)p * d.ldc : nullptr; };
-        if (d.border_add == nullptr && d.res_add == nullptr) {
-            store_tile_via_lds<T, MT, NT>(acc, scratch, lane, nullptr, d.act, d.slope, rowp, so, min(64, HoWo - pw), NoRowAdd(), ehook);   // ehook: diagnostic stamp
+        if (d.border_add == nullptr && d.res_add == nullptr && (NT != 4 || !BSTE || d.bst_partial == nullptr)) {
+            store_tile_via_lds<T, MT, NT>(acc, scratch, lane, nullptr, d.act, d.slope, rowp, so, min(64, HoWo - pw), NoRowAdd(), ehook, d.fin.tickets != nullptr);   // ehook: diagnostic stamp
         } else if constexpr (NT == 4) {
             // reflection-pad dgrad: add the mirrored-border terms (phases T,B,L,R,TL,TR,BL,BR of the compact border buffer)
             constexpr int E = ElemTraits<T>::E;
@@ -117,17 +120,20 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
                 // rows in flight: a ring of ND prefetch slots, refilled as rows are stored.  With border terms 2 and 4 measure the same
                 // and 4 spills with the statistics path; without them (mirror-pixel kernel: one chunk per row) all 8 rows are fetched up
                 // front - the ring of 2 left ~4 exposed round trips: 6.7k cycles per tile by the stamps
-                constexpr int ND = BORD ? 2 : 8;
+                constexpr int ND = BORD ? 2 : (BSTE ? 4 : 8);        // with the norm-backward statistics: a ring of 4 residual rows (registers)
                 const int c = lane % 8, r0 = lane / 8;
                 auto boff = [&](int phase, int pos) -> int {
                     return (int)(((((long)img * 8 + phase) * S + pos) * d.ldc + nw0 + c * E) * (long)sizeof(T));
                 };
                 // statistics of the InstanceNorm backward that takes this output as its dy (bst_*): the norm's saved input is
                 // prefetched like the residual; (sum g, sum g * xhat) of the lane's 8 channels over its 8 rows, combined below
-                const bool bst = BORD && d.bst_partial != nullptr && pw < HoWo;         // wave-uniform; not in the mirror-pixel kernel (refused on the host)
+                const bool bst = BSTE && d.bst_partial != nullptr && pw < HoWo;         // wave-uniform (round 4: a variant of the mirror-pixel kernel carries them too)
                 const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<void*>(bst ? d.bst_x : (hasr ? d.res_add : d.border_add)), 0, bst ? (unsigned)((long)d.B * HoWo * d.ldc * (int)sizeof(T)) : 0u, 0x00020000);
-                constexpr int NDX = 2;                                 // ring of the norm's-input chunks (bst_* statistics)
+                // ring of the norm's-input chunks (bst_* statistics).  Mirror-pixel kernel: all 8 rows are requested BEFORE the LDS transposition
+                // (the fragment registers of the K loop are free by then, the accumulators still live): the tensor comes from HBM (the forward
+                // pass wrote it long ago) and nothing else of the epilogue can hide that round trip
+                constexpr int NDX = BORD ? 2 : 8;
                 u32x4_t pre[ND][BORD ? 2 : 1], prex[NDX];              // [border term (line or column),] residual tensor; the norm's input
                 constexpr int PR = BORD ? 1 : 0;                       // slot of the residual chunk
                 unsigned both = 0;                                     // bit i: row i is one of the image's four double-border pixels
@@ -153,6 +159,12 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
                 constexpr int ND0 = 2;                                 // fetched NOW, behind the LDS transposition (accumulators still live); the rest in mid()
 #pragma unroll
                 for (int i = 0; i < ND0; ++i) fetch(i);
+                if constexpr (!BORD && BSTE) {
+                    if (bst) {
+#pragma unroll
+                        for (int i = 0; i < NDX; ++i) fetch_x(i);
+                    }
+                }
                 float bmu[E], brs[E], bs1[E], bs2[E];
 #pragma unroll
                 for (int e = 0; e < E; ++e) { bmu[e] = 0.f; brs[e] = 0.f; bs1[e] = 0.f; bs2[e] = 0.f; }
@@ -167,8 +179,10 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
                         const f32x4_t t4 = *reinterpret_cast<const f32x4_t*>(sp + 2 * e);
                         bmu[e] = t4[0]; brs[e] = t4[1]; bmu[e + 1] = t4[2]; brs[e + 1] = t4[3];
                     }
+                    if constexpr (BORD) {
 #pragma unroll
-                    for (int i = 0; i < NDX; ++i) fetch_x(i);
+                        for (int i = 0; i < NDX; ++i) fetch_x(i);
+                    }
                 };
                 auto add = [&](int r, int, const u32x4_t& v, int i) -> u32x4_t {
                     float f[E], g[E];
@@ -212,7 +226,7 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
                     if (bst && i + NDX < NI) fetch_x(i + NDX);
                     return outc;
                 };
-                store_tile_via_lds<T, MT, NT>(acc, scratch, lane, nullptr, d.act, d.slope, rowp, so, min(64, HoWo - pw), add, mid);
+                store_tile_via_lds<T, MT, NT>(acc, scratch, lane, nullptr, d.act, d.slope, rowp, so, min(64, HoWo - pw), add, mid, d.fin.tickets != nullptr);
                 if (bst) {                                             // combine the 8 lanes that hold the same chunk; lanes 0-7 write
 #pragma unroll
                     for (int o = 8; o < 64; o <<= 1)
@@ -220,8 +234,13 @@ __device__ __forceinline__ void strip_epilogue(const f32x4_t (&acc)[NT][MT], uns
                         for (int e = 0; e < E; ++e) { bs1[e] += __shfl_xor(bs1[e], o, 64); bs2[e] += __shfl_xor(bs2[e], o, 64); }
                     if (lane < 8) {
                         float* o = d.bst_partial + (((long)img * ((HoWo + 63) / 64) + pw / 64) * d.Nstore + nw0 + lane * E) * 2;
+                        if (d.bfin.tickets != nullptr) {               // finalised inside this launch: write-through stores
 #pragma unroll
-                        for (int e = 0; e < E; e += 2) *reinterpret_cast<f32x4_t*>(o + 2 * e) = f32x4_t{bs1[e], bs2[e], bs1[e + 1], bs2[e + 1]};
+                            for (int e = 0; e < E; ++e) uig_store8_sc1(o + 2 * e, bs1[e], bs2[e]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < E; e += 2) *reinterpret_cast<f32x4_t*>(o + 2 * e) = f32x4_t{bs1[e], bs2[e], bs1[e + 1], bs2[e + 1]};
+                        }
                     }
                 }
             } else {

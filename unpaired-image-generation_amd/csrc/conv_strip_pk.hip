@@ -58,7 +58,7 @@
 // NOZ (round 3): no zero rows behind the strip - for launches that never read one (reflection padding, whole tiles): the strip may then
 // be CAP = 512 rows (2 x 80 KB of LDS exactly, 16-bit row table up to 65,520), i.e. a 256-pixel tile of a 128-pixel-wide map (two
 // image rows + two halo rows): the ResBlock forward convolutions of the 512x512 configuration on this kernel instead of the generic one.
-template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false, bool MIRROR = false, bool NORM = false, bool NOZ = false, int NISS = 8, bool PKRT = false>
+template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false, bool MIRROR = false, bool NORM = false, bool NOZ = false, int NISS = 8, bool PKRT = false, bool BST = false>
 __global__ __launch_bounds__(512, 2)
 void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, const float* __restrict__ bias1, T* __restrict__ y,
                           const StripDesc d) {
@@ -536,7 +536,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
             stamp();
             strip_epilogue<T, MT, NT, WM, WN, !MIRROR>(acc, scratch, d, y, cur.img, cur.p0, wm, wn, cur.n_base, lane_e, stamp);
         } else
-        strip_epilogue<T, MT, NT, WM, WN, !MIRROR>(acc, scratch, d, y, cur.img, cur.p0, wm, wn, cur.n_base, lane_e);
+        strip_epilogue<T, MT, NT, WM, WN, !MIRROR, NoMidHook, !MIRROR || BST>(acc, scratch, d, y, cur.img, cur.p0, wm, wn, cur.n_base, lane_e);
         stamp();                                               // 3 / 6: epilogue issued
         if (!nxt.valid) break;
         if constexpr (XPREF) {
@@ -553,6 +553,19 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
             issue_first(nxt, 0);
         }
         cur = nxt;
+    }
+    // round 4: no finalize launch behind this one - one arrival ticket per tile and image once ALL of this block's tiles are out (nothing
+    // is added to a tile's epilogue; the block's stores must drain before it exits anyway); the block that draws an image's last ticket
+    // reduces that image's statistics slabs (uig_common.h, UigFin).  All LDS is free here: word 0 carries the "I am last" flag.
+    if (d.fin.tickets != nullptr || d.bfin.tickets != nullptr) {          // launch-uniform
+        int tid_e = threadIdx.x;                                           // opaque: nothing derived from it here may be hoisted above the tile loop
+        asm volatile("" : "+v"(tid_e));
+        for (int r = 0;; ++r) {
+            const Tile t = get_tile(r);
+            if (!t.valid) break;                                           // block-uniform
+            if (d.fin.tickets != nullptr) uig_fin_arrive<64 * NW>(d.fin, t.img, 1u, reinterpret_cast<unsigned*>(smem), tid_e);
+            if (d.bfin.tickets != nullptr) uig_fin_arrive<64 * NW>(d.bfin, t.img, 1u, reinterpret_cast<unsigned*>(smem), tid_e);
+        }
     }
     if constexpr (STAMP) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -577,10 +590,10 @@ static int device_cus() {
     return n;
 }
 
-template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false, bool MIRROR = false, bool NORM = false, bool NOZ = false, int NISS = 8, bool PKRT = false>
+template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false, bool MIRROR = false, bool NORM = false, bool NOZ = false, int NISS = 8, bool PKRT = false, bool BST = false>
 static int launch_pk(const void* x, const void* wp, const float* bias, void* y, const StripDesc& d, int ntiles, hipStream_t s) {
     const size_t smem = 2 * ((size_t)(CAP + (NOZ ? 0 : 8)) * 128 + 128 * 128) + (NORM ? (size_t)4 * 256 * 8 : 0);      // NORM: (mean, rstd) of 4 images x <= 256 channels
-    auto kern = conv_strip_pk_kernel<T, CAP, DM, SWZ, LGK, STAMP, MIRROR, NORM, NOZ, NISS, PKRT>;
+    auto kern = conv_strip_pk_kernel<T, CAP, DM, SWZ, LGK, STAMP, MIRROR, NORM, NOZ, NISS, PKRT, BST>;
     static SmemAttrOnce attr_once;
     {
         hipError_t e = attr_once.ensure(reinterpret_cast<const void*>(kern), smem);
@@ -617,6 +630,11 @@ int uig_launch_strip_pk(const void* x, const void* wp, const float* bias, void* 
     if (dtype == UIG_BF16) {
         if (d.mirror) {
             if (d.dbg != nullptr) return launch_pk<bf16_t, 448, 0, 1, true, true, true>(x, wp, bias, y, d, ntiles, s);
+            // round 4: the variant whose epilogue also emits the statistics of the InstanceNorm backward that consumes dx
+            if (d.bst_partial != nullptr) {
+                if (g_pk_dm == 31) return launch_pk<bf16_t, 448, 5, 1, true, false, true, false, false, 4, false, true>(x, wp, bias, y, d, ntiles, s);   // plain row table (A/B: spills a few registers around the epilogue)
+                return launch_pk<bf16_t, 448, 5, 1, true, false, true, false, false, 4, true, true>(x, wp, bias, y, d, ntiles, s);                        // packed row table: room for the epilogue's prefetches
+            }
             switch (g_pk_dm) {
                 case 12: return launch_pk<bf16_t, 448, 0, 1, true, false, true>(x, wp, bias, y, d, ntiles, s);
                 case 20: return launch_pk<bf16_t, 448, 5, 1, true, false, true, false, false, 4, true>(x, wp, bias, y, d, ntiles, s);

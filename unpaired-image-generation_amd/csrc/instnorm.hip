@@ -11,7 +11,7 @@
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                         const float* __restrict__ stats, float* __restrict__ partial,
-                                                        long HW, int C, int CC, int nslab, int act, float slope) {
+                                                        long HW, int C, int CC, int nslab, int act, float slope, const UigFin fin = UigFin{}) {
     constexpr int E = ElemTraits<T>::E;
     __shared__ float red[256 * E * 2];
     const int tid = threadIdx.x;
@@ -55,8 +55,11 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ x, 
         float a = 0.f, q = 0.f;
         for (int l = 0; l < PL; ++l) { a += red[(l * C + c) * 2]; q += red[(l * C + c) * 2 + 1]; }
         float* out = partial + (((long)b * nslab + slab) * C + c) * 2;
-        out[0] = a; out[1] = q;
+        if (fin.tickets != nullptr) uig_store8_sc1(out, a, q);      // block-uniform: read back inside this launch by the image's last arriver
+        else { out[0] = a; out[1] = q; }
     }
+    // round 4: no finalize launch - the image's last-arriving block finalises (uig_common.h, UigFin); red[] is free behind the barrier
+    if (fin.tickets != nullptr) uig_fin_arrive<256>(fin, b, 1u, reinterpret_cast<unsigned*>(red), tid);
 }
 
 // fin MODE 0: stats = (mean, rstd)   MODE 1: out = (mean_g, mean_gxhat)   MODE 2: db[c] (+)= sum (B folded into slabs)
@@ -379,7 +382,24 @@ extern "C" int uig_instnorm_act_fwd(const void* x, const void* residual, void* y
     return 0;
 }
 
-static int colsum_slabs(long HW, int CC) { return (int)std::max<long>(1, std::min<long>(32, HW * CC / (256 * 4))); }
+// UigFin of a stand-alone statistics pass with ns slabs per image (one arrival per block)
+static UigFin make_fin(float* out, unsigned* tickets, const float* partial, int ns, int C, long HW, float eps, int mode) {
+    UigFin f{};
+    f.out = out; f.tickets = tickets; f.partial = partial; f.nslab = ns; f.C = C; f.expected = (unsigned)ns; f.mode = mode | uig_in_tickets_dbg(); f.eps = eps;
+    f.inv_n = 1.0 / (double)HW;
+    return f;
+}
+static int g_in_tickets = 1;    // A/B and parity hook: 0 = the ticketed entry points run the finalize LAUNCH instead (bit-identical results)
+extern "C" void uig_debug_set_in_tickets(int on) { g_in_tickets = on; }
+bool uig_in_tickets_on() { return g_in_tickets != 0; }
+int uig_in_tickets_dbg() { return g_in_tickets == 2 ? 16 : (g_in_tickets == 3 ? 32 + 16 : 0); }      // 2: arrive, skip the reduction; 3: no ticket either (timing only)
+
+// pixel slabs (= blocks) per image of the backward apply pass that also emits the column sums.  Round 4 A/B in the full step (one box,
+// two rounds): 32 -> 13.53-13.56 ms, 64 -> 13.56, 128 -> 14.04-14.09, 256 -> 14.17: more slabs buy no bandwidth and cost the
+// column-sum partials' reduce (bias rider of the weight-gradient reduce).  32 stays.
+static int g_colsum_slabs = 32;
+extern "C" void uig_debug_set_colsum_slabs(int n) { g_colsum_slabs = n > 0 ? n : 32; }
+static int colsum_slabs(long HW, int CC) { return (int)std::max<long>(1, std::min<long>(g_colsum_slabs, HW * CC / (256 * 4))); }
 extern "C" int uig_instnorm_bwd_colsum_slabs(int B, int64_t HW, int C, int dtype) {
     const int E = dtype == UIG_BF16 ? 8 : 4;
     return B * colsum_slabs(HW, C / E);
@@ -387,24 +407,33 @@ extern "C" int uig_instnorm_bwd_colsum_slabs(int B, int64_t HW, int C, int dtype
 
 static int instnorm_bwd_impl(const void* dy, const void* x, const float* stats, void* dx, float* workspace, float* colsum_partial,
                              int B, int64_t HW, int C, int act, float slope, int dtype, void* stream,
-                             unsigned char* mxq = nullptr, unsigned char* mxs = nullptr, const float* pre_partial = nullptr, int pre_nslab = 0) {
+                             unsigned char* mxq = nullptr, unsigned char* mxs = nullptr, const float* pre_partial = nullptr, int pre_nslab = 0,
+                             unsigned* tickets = nullptr, const float* pre_gm = nullptr) {
     UIG_CHECK_ARG(dy && x && stats && dx && workspace, "uig_instnorm_act_bwd: null pointer");
     UIG_CHECK_ARG(act == UIG_ACT_NONE || act == UIG_ACT_RELU || act == UIG_ACT_LRELU, "uig_instnorm_act_bwd: bad act %d", act);
     int CC; if (int r = check_in_args("uig_instnorm_act_bwd", B, HW, C, dtype, &CC)) return r;
     hipStream_t s = (hipStream_t)stream;
     const int ns = stats_slabs(HW, CC), na = colsum_partial ? colsum_slabs(HW, CC) : apply_slabs(HW, CC);
-    float* gm = workspace + (size_t)B * 128 * C * 2;
-    if (pre_partial == nullptr) {
-        if (dtype == UIG_BF16)
-            hipLaunchKernelGGL((in_stats_kernel<bf16_t, 1>), dim3(ns, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, stats, workspace, (long)HW, C, CC, ns, act, slope);
-        else
-            hipLaunchKernelGGL((in_stats_kernel<float, 1>), dim3(ns, B), dim3(256), 0, s, (const float*)x, (const float*)dy, stats, workspace, (long)HW, C, CC, ns, act, slope);
-        UIG_LAUNCH_CHECK("uig_instnorm_act_bwd(stats)");
+    const float* gm = pre_gm;      // (mean g, mean g*xhat) already finalised inside the launch that wrote dy (round 4)
+    if (gm == nullptr) {
+        float* gmw = workspace + (size_t)B * 128 * C * 2;
+        gm = gmw;
+        const bool tk = tickets != nullptr && g_in_tickets && pre_partial == nullptr;      // the statistics pass finalises itself: no finalize launch
+        const UigFin fin = tk ? make_fin(gmw, tickets, workspace, ns, C, (long)HW, 0.f, 1) : UigFin{};
+        if (pre_partial == nullptr) {
+            if (dtype == UIG_BF16)
+                hipLaunchKernelGGL((in_stats_kernel<bf16_t, 1>), dim3(ns, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, stats, workspace, (long)HW, C, CC, ns, act, slope, fin);
+            else
+                hipLaunchKernelGGL((in_stats_kernel<float, 1>), dim3(ns, B), dim3(256), 0, s, (const float*)x, (const float*)dy, stats, workspace, (long)HW, C, CC, ns, act, slope, fin);
+            UIG_LAUNCH_CHECK("uig_instnorm_act_bwd(stats)");
+        }
+        if (!tk) {
+            // (sum g, sum g*xhat) partials: this norm's own statistics pass, or the epilogue of the launch that wrote dy
+            hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 15) / 16), dim3(256), 0, s, pre_partial ? pre_partial : workspace, gmw, B * C, C,
+                               pre_partial ? pre_nslab : ns, 1.0 / (double)HW, 0.f, 1, 0, 0);
+            UIG_LAUNCH_CHECK("uig_instnorm_act_bwd(finalize)");
+        }
     }
-    // (sum g, sum g*xhat) partials: this norm's own statistics pass, or the epilogue of the launch that wrote dy
-    hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 15) / 16), dim3(256), 0, s, pre_partial ? pre_partial : workspace, gm, B * C, C,
-                       pre_partial ? pre_nslab : ns, 1.0 / (double)HW, 0.f, 1, 0, 0);
-    UIG_LAUNCH_CHECK("uig_instnorm_act_bwd(finalize)");
     if (colsum_partial) {
         if (dtype == UIG_BF16)
             hipLaunchKernelGGL((in_apply_bwd_kernel<bf16_t, true>), dim3(na, B), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, stats, gm, colsum_partial, (long)HW, C, CC, na, act, slope, mxq, mxs);
@@ -444,6 +473,14 @@ extern "C" int uig_instnorm_finalize(const float* partial, int nslab, float* sta
     UIG_CHECK_ARG(partial && stats && nslab > 0 && B > 0 && C > 0 && HW > 0, "uig_instnorm_finalize: bad arguments");
     hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, stats, B * C, C, nslab, 1.0 / (double)HW, eps, 0, 0, 0);
     UIG_LAUNCH_CHECK("uig_instnorm_finalize");
+    return 0;
+}
+
+// the backward counterpart: (sum g, sum g*xhat) partials -> gm fp32[B][C][2] = (mean g, mean g*xhat)
+int uig_instnorm_finalize_bwd(const float* partial, int nslab, float* gm, int B, int64_t HW, int C, void* stream) {
+    UIG_CHECK_ARG(partial && gm && nslab > 0 && B > 0 && C > 0 && HW > 0, "uig_instnorm_finalize_bwd: bad arguments");
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, gm, B * C, C, nslab, 1.0 / (double)HW, 0.f, 1, 0, 0);
+    UIG_LAUNCH_CHECK("uig_instnorm_finalize_bwd");
     return 0;
 }
 
@@ -568,4 +605,66 @@ extern "C" int uig_instnorm_act_bwd_colsum_pre(const void* dy, const void* x, co
     if (mx_q != nullptr) UIG_CHECK_ARG(dtype == UIG_BF16 && C % 32 == 0, "uig_instnorm_act_bwd_colsum_pre: MX output needs bf16 and C %% 32 == 0 (C=%d)", C);
     return instnorm_bwd_impl(dy, x, stats, dx, workspace, colsum_partial, B, HW, C, act, slope, dtype, stream,
                              (unsigned char*)mx_q, (unsigned char*)mx_s, partial, nslab);
+}
+
+// ---- round 4: the same operators without the finalize LAUNCH (in-launch finalize by arrival tickets: uig_common.h, UigFin).
+// tickets: >= B zero-initialised 32-bit words the launch leaves zero (the caller's arena; one per image).  Results are bit-identical to
+// the entry points above (same slabs, same fp64 association order).
+
+// forward, statistics already FINAL (stats fp32[B][C][2] = (mean, rstd): produced inside the convolution launch, uig_conv_gather_fin):
+// the apply launch alone.  mx_q / mx_s optional (both or none; bf16, C % 32 == 0): as uig_instnorm_act_fwd_mx.
+extern "C" int uig_instnorm_apply_fwd(const void* x, const void* residual, void* y, const float* stats, void* mx_q, void* mx_s,
+                                      int B, int64_t HW, int C, int act, float slope, int dtype, void* stream) {
+    UIG_CHECK_ARG(x && y && stats, "uig_instnorm_apply_fwd: null pointer");
+    UIG_CHECK_ARG(act == UIG_ACT_NONE || act == UIG_ACT_RELU || act == UIG_ACT_LRELU, "uig_instnorm_apply_fwd: bad act %d", act);
+    UIG_CHECK_ARG((mx_q == nullptr) == (mx_s == nullptr), "uig_instnorm_apply_fwd: mx_q and mx_s go together");
+    if (mx_q != nullptr) UIG_CHECK_ARG(dtype == UIG_BF16 && C % 32 == 0, "uig_instnorm_apply_fwd: MX output needs bf16 and C %% 32 == 0 (C=%d)", C);
+    int CC; if (int r = check_in_args("uig_instnorm_apply_fwd", B, HW, C, dtype, &CC)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    const int na = apply_slabs(HW, CC);
+    if (dtype == UIG_BF16)
+        hipLaunchKernelGGL((in_apply_fwd_kernel<bf16_t>), dim3(na, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, stats, (long)HW, C, CC, na, act, slope,
+                           (unsigned char*)mx_q, (unsigned char*)mx_s);
+    else
+        hipLaunchKernelGGL((in_apply_fwd_kernel<float>), dim3(na, B), dim3(256), 0, s, (const float*)x, (const float*)residual, (float*)y, stats, (long)HW, C, CC, na, act, slope);
+    UIG_LAUNCH_CHECK("uig_instnorm_apply_fwd");
+    return 0;
+}
+
+// forward with its own statistics pass, which finalises itself (two launches instead of three).  mx_q / mx_s optional.
+extern "C" int uig_instnorm_act_fwd_t(const void* x, const void* residual, void* y, float* stats, float* workspace, unsigned* tickets,
+                                      void* mx_q, void* mx_s, int B, int64_t HW, int C, float eps, int act, float slope, int dtype, void* stream) {
+    UIG_CHECK_ARG(x && y && stats && workspace && tickets, "uig_instnorm_act_fwd_t: null pointer");
+    UIG_CHECK_ARG(act == UIG_ACT_NONE || act == UIG_ACT_RELU || act == UIG_ACT_LRELU, "uig_instnorm_act_fwd_t: bad act %d", act);
+    int CC; if (int r = check_in_args("uig_instnorm_act_fwd_t", B, HW, C, dtype, &CC)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    const int ns = stats_slabs(HW, CC);
+    const UigFin fin = g_in_tickets ? make_fin(stats, tickets, workspace, ns, C, (long)HW, eps, 0) : UigFin{};
+    if (dtype == UIG_BF16)
+        hipLaunchKernelGGL((in_stats_kernel<bf16_t, 0>), dim3(ns, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, workspace, (long)HW, C, CC, ns, 0, 0.f, fin);
+    else
+        hipLaunchKernelGGL((in_stats_kernel<float, 0>), dim3(ns, B), dim3(256), 0, s, (const float*)x, (const float*)nullptr, (const float*)nullptr, workspace, (long)HW, C, CC, ns, 0, 0.f, fin);
+    UIG_LAUNCH_CHECK("uig_instnorm_act_fwd_t(stats)");
+    if (!g_in_tickets) {
+        hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 15) / 16), dim3(256), 0, s, workspace, stats, B * C, C, ns, 1.0 / (double)HW, eps, 0, 0, 0);
+        UIG_LAUNCH_CHECK("uig_instnorm_act_fwd_t(finalize)");
+    }
+    return uig_instnorm_apply_fwd(x, residual, y, stats, mx_q, mx_s, B, HW, C, act, slope, dtype, stream);
+}
+
+// backward (+ column-sum partials of dx, + optional MX form of dx).  Where (mean g, mean g*xhat) come from:
+//   pre_gm != NULL      fp32[B][C][2], already final (finalised inside the launch that wrote dy): the apply launch alone;
+//   pre_partial != NULL that launch's epilogue partials (pre_nslab per image): finalize launch + apply (uig_instnorm_act_bwd_colsum_pre);
+//   neither             this norm's own statistics pass, finalising itself through `tickets` (two launches instead of three).
+extern "C" int uig_instnorm_act_bwd_colsum_t(const void* dy, const void* x, const float* stats, void* dx, float* workspace,
+                                             float* colsum_partial, const float* pre_partial, int pre_nslab, const float* pre_gm,
+                                             unsigned* tickets, void* mx_q, void* mx_s,
+                                             int B, int64_t HW, int C, int act, float slope, int dtype, void* stream) {
+    UIG_CHECK_ARG(colsum_partial, "uig_instnorm_act_bwd_colsum_t: null colsum_partial");
+    UIG_CHECK_ARG(pre_gm || pre_partial || tickets, "uig_instnorm_act_bwd_colsum_t: needs pre_gm, pre_partial or tickets");
+    UIG_CHECK_ARG(pre_partial == nullptr || pre_nslab > 0, "uig_instnorm_act_bwd_colsum_t: pre_nslab=%d", pre_nslab);
+    UIG_CHECK_ARG((mx_q == nullptr) == (mx_s == nullptr), "uig_instnorm_act_bwd_colsum_t: mx_q and mx_s go together");
+    if (mx_q != nullptr) UIG_CHECK_ARG(dtype == UIG_BF16 && C % 32 == 0, "uig_instnorm_act_bwd_colsum_t: MX output needs bf16 and C %% 32 == 0 (C=%d)", C);
+    return instnorm_bwd_impl(dy, x, stats, dx, workspace, colsum_partial, B, HW, C, act, slope, dtype, stream,
+                             (unsigned char*)mx_q, (unsigned char*)mx_s, pre_partial, pre_nslab, tickets, pre_gm);
 }

@@ -84,6 +84,123 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// In-launch finalize of InstanceNorm statistics (round 4).  The kernels that produce an image's partial statistics slabs
+// (convolution epilogues, the stand-alone statistics pass) used to be followed by a finalize LAUNCH (in_finalize_kernel: 112 per train
+// step, 5.3 us each, almost all of it launch boundary).  Here every block takes an ARRIVAL TICKET per image after its slabs are out;
+// the block that draws the image's last ticket reduces that image's slabs itself, in exactly in_finalize_kernel's association order
+// (16 slab lanes per channel, sequential fp64 sums, xor-shuffle tree): bit-identical (mean, rstd), no extra launch.
+// Protocol (cdna_hip_programming.md, "In-launch split-K reduction", sc1 form - a release fence per tile would write back the XCD's
+// whole dirty L2, output tile included: 6.5 us): slabs are stored WRITE-THROUGH (sc1: 8-byte agent-scope relaxed atomic stores), every
+// storing wave drains its stores (s_waitcnt vmcnt(0)), the block's barrier, ONE relaxed agent-scope fetch_add by one lane; the last
+// arriver reads the slabs with sc1 loads only (agent-scope relaxed atomic loads: never served by this CU's L1, no acquire fence
+// needed).  One ticket per block and image, not per element.  The ticket words are zero between launches: the last arriver resets its
+// word (plus one memset per step by the owner of the arena, so that an aborted launch cannot poison the next step).
+struct UigFin {
+    float* out;               // fp32[B][C][2]: mode 0 (mean, rstd), mode 1 (mean g, mean g*xhat)
+    unsigned* tickets;        // [>= B] zero on entry, zero on exit
+    const float* partial;     // fp32[B][nslab][C][2], written by THIS launch with uig_store8_sc1
+    int nslab, C;
+    unsigned expected;        // sum of the arrival counts of one image
+    int mode; float eps;
+    double inv_n;
+};
+
+__device__ __forceinline__ void uig_store8_sc1(float* p, float a, float b) {      // p 8-byte aligned
+    const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long uig_load8_sc1(const float* p) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// all NTHREADS threads of the block; bit-identical to in_finalize_kernel (modes 0 / 1) on image `img`.
+// 16 slab lanes per channel PAIR (one 16-byte sc1 load = both channels' (sum, sum^2) of one slab); the loads of four passes x four slab
+// rounds are issued before the first sum (the last arriver is alone with a cold 128-KB read: its time is round trips, not bytes - the
+// first form, one pass of four loads at a time, cost 20 us per convolution launch); slab rows past nslab are read out of the buffer's
+// range (zeros: x + 0.0 == x for the never-negative-zero partial sums).  Sums per channel in slab order, then the xor-shuffle tree.
+template <int NTHREADS>
+__device__ __forceinline__ void uig_fin_image(const UigFin& f, int img, int tid) {
+    static_assert(NTHREADS % 64 == 0, "whole waves");
+    constexpr int IPP = NTHREADS / 16, PU = 4, SU = 4;   // channel pairs per pass; passes / slab rounds in flight together
+    const int sl = tid & 15, it = tid >> 4;
+    const int npair = f.C >> 1;
+    const unsigned rowb = (unsigned)f.C * 8u, imgb = (unsigned)f.nslab * rowb;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f.partial + (long)img * f.nslab * f.C * 2), 0, imgb, 0x00020000);
+    for (int p0 = 0; p0 < npair; p0 += IPP * PU) {
+        double acc[PU][4];
+        unsigned poff[PU];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            acc[u][0] = acc[u][1] = acc[u][2] = acc[u][3] = 0.0;
+            poff[u] = (unsigned)min(p0 + u * IPP + it, npair - 1) * 16u;      // clamped: a pair past the end re-reads the last one, never stored
+        }
+        for (int s0 = 0; s0 < f.nslab; s0 += 16 * SU) {
+            u32x4_t v[PU][SU];
+#pragma unroll
+            for (int k = 0; k < SU; ++k) {
+                const int srow = s0 + 16 * k + sl;
+                const unsigned ro = srow < f.nslab ? (unsigned)srow * rowb : imgb;      // out of range -> zeros
+#pragma unroll
+                for (int u = 0; u < PU; ++u)
+                    v[u][k] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ro + (srow < f.nslab ? poff[u] : 0u)), 0, 16));   // aux 16 = sc1
+            }
+#pragma unroll
+            for (int k = 0; k < SU; ++k)
+#pragma unroll
+                for (int u = 0; u < PU; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[u][e] += (double)__uint_as_float(v[u][k][e]);
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < PU; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[u][e] += __shfl_xor(acc[u][e], o, 16);
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const int pr = p0 + u * IPP + it;
+            if (sl == 0 && pr < npair) {
+                float r[4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const double a = acc[u][2 * h], q = acc[u][2 * h + 1];
+                    if ((f.mode & 15) == 0) {
+                        const double mean = a * f.inv_n;
+                        double var = q * f.inv_n - mean * mean;
+                        if (var < 0.0) var = 0.0;
+                        r[2 * h] = (float)mean; r[2 * h + 1] = (float)(1.0 / sqrt(var + (double)f.eps));
+                    } else {
+                        r[2 * h] = (float)(a * f.inv_n); r[2 * h + 1] = (float)(q * f.inv_n);
+                    }
+                }
+                *reinterpret_cast<f32x4_t*>(f.out + ((long)img * f.C + 2 * pr) * 2) = f32x4_t{r[0], r[1], r[2], r[3]};
+            }
+        }
+    }
+}
+
+// Called by ALL threads of the block (block-uniform arguments) after the block's slabs of image `img` were stored with
+// uig_store8_sc1; `count` = this block's share of f.expected; lds_word = any 4-byte LDS word nobody else uses around the call.
+template <int NTHREADS>
+__device__ __forceinline__ void uig_fin_arrive(const UigFin& f, int img, unsigned count, unsigned* lds_word, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's slab stores are through
+    __syncthreads();                                       // ... and every other wave's of the block
+    const int dbg = f.mode >> 4;                          // timing diagnostics only (uig_debug_set_in_tickets 2 / 3): wrong statistics
+    if (tid == 0) {
+        unsigned last = 0u;
+        if (!(dbg & 2)) {
+            const unsigned old = __hip_atomic_fetch_add(f.tickets + img, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (old + count == f.expected) ? 1u : 0u;
+            if (last) __hip_atomic_store(f.tickets + img, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *reinterpret_cast<volatile unsigned*>(lds_word) = last;
+    }
+    __syncthreads();
+    if (*reinterpret_cast<volatile unsigned*>(lds_word) != 0u && !(dbg & 1)) uig_fin_image<NTHREADS>(f, img, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Output-tile store through LDS for the MFMA conv kernels.  After the MFMAs a lane holds 4 consecutive channels of one
 // pixel per 16x16 tile; storing those directly is 16 scattered 8-byte stores per lane (measured: 26 % of the kernel).
 // Instead each wave writes its 64-pixel x 64-channel tile (bias + activation applied, converted to T) into its own LDS
@@ -103,7 +220,7 @@ template <typename T, int MT, int NT, typename RowPtr, typename RowAdd = NoRowAd
 __device__ __forceinline__ void store_tile_via_lds(const f32x4_t (&acc)[NT][MT], unsigned char* scratch, int lane,
                                                    const float* bias4 /* NT*4 bias values of this lane, or nullptr */,
                                                    int act, float slope, RowPtr row_ptr, float* stat_out = nullptr,
-                                                   int nvalid = 64, RowAdd row_add = RowAdd(), MidHook mid = MidHook()) {
+                                                   int nvalid = 64, RowAdd row_add = RowAdd(), MidHook mid = MidHook(), bool stat_sc1 = false) {
     static_assert(MT == 4 && (NT == 4 || NT == 2 || NT == 1) && NT * 16 * sizeof(T) >= 32, "64-pixel x 64- / 32- / 16-channel wave tile");
     constexpr int ROWB = NT * 16 * (int)sizeof(T);     // bytes per pixel row of the wave tile: 128 (bf16) / 256 (f32) at 64 channels; 32 at 16 bf16 channels
     constexpr int NCH = ROWB / 16;                     // 16-byte chunks per row
@@ -169,8 +286,13 @@ __device__ __forceinline__ void store_tile_via_lds(const f32x4_t (&acc)[NT][MT],
             for (int e = 0; e < EC; ++e) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
         if (lane < NCH) {                              // lane c holds channels c*EC .. c*EC+EC-1: 2*EC contiguous floats
             float* o = stat_out + lane * EC * 2;
+            if (stat_sc1) {                            // wave-uniform: an in-launch finalize reads them (UigFin): write-through stores
 #pragma unroll
-            for (int e = 0; e < EC; e += 2) *reinterpret_cast<f32x4_t*>(o + 2 * e) = f32x4_t{s1[e], s2[e], s1[e + 1], s2[e + 1]};
+                for (int e = 0; e < EC; ++e) uig_store8_sc1(o + 2 * e, s1[e], s2[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < EC; e += 2) *reinterpret_cast<f32x4_t*>(o + 2 * e) = f32x4_t{s1[e], s2[e], s1[e + 1], s2[e + 1]};
+            }
         }
     }
 }
@@ -202,6 +324,13 @@ __device__ __forceinline__ u32x2_t mx_quantize8(const float* f, int& sbyte) {
     sbyte = sb;
     return u32x2_t{w[0], w[1]};
 }
+
+// optional requests that ride on a uig_conv_gather* launch; `done` is set by the kernel family that served the request inside its
+// launch - conv_gather_impl runs the finalize launch for whatever is left (the results are bit-identical either way)
+struct UigBst { const void* x; const float* stats; float* partial; int act; float slope; float* gm; unsigned* tickets; int done; };
+struct UigFinReq { float* stats; float eps; unsigned* tickets; int done; };
+bool uig_in_tickets_on();      // instnorm.hip: the A/B hook uig_debug_set_in_tickets
+int uig_in_tickets_dbg();
 
 // host-side error plumbing (defined in uig_capi.hip)
 int uig_set_error(int code, const char* fmt, ...);

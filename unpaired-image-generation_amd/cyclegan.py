@@ -71,6 +71,8 @@ class CycleGAN:
         self.n_stages_G = int(os.environ.get("UIG_DP_STAGES_G", "4"))
         self.n_stages_D = int(os.environ.get("UIG_DP_STAGES_D", "2"))
         self._graphs = None
+        if self.device.type == "cuda":
+            ops.ticket_arena(self.device)               # arrival-ticket words of the in-launch statistics finalize: before any graph capture
         self._finalize_params()
 
     # ------------------------------------------------------------------ parameters
@@ -151,6 +153,7 @@ class CycleGAN:
         taps = {i: None for i in self.cuts_G} if self.cuts_G else None
         self.grp_D.set_requires_grad(False)
         self.grp_G.zero_grad()
+        ops.reset_tickets(self.device)                  # one fill per step (every ticketed launch leaves its words zero anyway)
         if self.batch_fused and self.paired:
             # G_A on [xb; xa] and G_B on [xb; xa] as ONE paired pass over 4B images -> [idt_A, fake_B | fake_A, idt_B]: the two
             # fakes are adjacent, so the batch [fake_B; fake_A] that feeds both the cycle pass and the discriminators is a view

@@ -29,6 +29,8 @@ class Translator:
         for p in generator.parameters():
             p.requires_grad_(False)
         generator.repack()
+        if self.device.type == "cuda":
+            ops.ticket_arena(self.device)             # before any graph capture (in-launch statistics finalize of batches > 2)
         self._ident = {}
 
     @classmethod

@@ -47,6 +47,7 @@ class ConvLayer(nn.Module):
         self._packed_version = None
         self.fuse_grad_accum = True    # backward adds dW/db into an existing .grad in place (see ops.ConvFn.backward)
         self.emit_in_stats = False     # set by the network builders for convs that feed an InstanceNorm
+        self.in_eps = 1e-5             # ... and that norm's eps (round 4: the convolution launch delivers (mean, rstd) final)
         self.fp8 = False               # enable_fp8(): forward + input gradient on the MX block-scaled fp8 kernel
 
     def enable_fp8(self):
@@ -159,7 +160,7 @@ class _PhysNet(nn.Sequential):
             mods = list(seq)
             for a, b in zip(mods, mods[1:]):
                 if isinstance(a, ConvLayer) and isinstance(b, InstNormAct):
-                    a.emit_in_stats = True
+                    a.emit_in_stats, a.in_eps = True, b.eps
                 if isinstance(a, ResBlock):
                     walk(a.b)
             if mods and isinstance(mods[-1], ResBlock):

@@ -35,6 +35,49 @@ FUSE_MX_QUANT = os.environ.get("UIG_FUSE_MX_QUANT", "1") != "0"            # fp8
 # ResBlock: conv2 applies the InstanceNorm + ReLU in front of it to its own input strip (NormConvFn): no apply pass between the block's two convolutions
 NORM_CONV = os.environ.get("UIG_NORM_CONV", "0") != "0"      # OFF by default: measured slower (13.64 vs 13.48 ms per step; g_fwd 2.45 vs 2.34 ms) - see DESIGN.md
 COMBINE_PASS_WGRAD = os.environ.get("UIG_COMBINE_PASS_WGRAD", "1") != "0"  # one weight-gradient launch per ResBlock conv pair for BOTH generator passes of a step
+# Round 4: InstanceNorm statistics are finalised INSIDE the launch that produces their partial slabs (arrival tickets: the image's
+# last-arriving block reduces the slabs; include/uig.h, uig_conv_gather_fin) instead of by a finalize launch (112 per train step,
+# 5.3 us each).  0 = the finalize launches (bit-identical results: A/B and the parity test).
+IN_TICKETS = os.environ.get("UIG_IN_TICKETS", "0") != "0"
+# Round 4: the mirror-pixel input-gradient launch of a ResBlock convolution also emits the statistics of the InstanceNorm backward that
+# consumes its output (and finalises them): that norm's own statistics pass (a full read of dy and x) and its finalize launch are gone.
+MIRROR_BST = os.environ.get("UIG_MIRROR_BST", "0") != "0"
+_TICKET_WORDS = 4096     # images per ticketed launch (one 32-bit word each) and family
+_TICKETS = {}            # device index -> zero int32 arena [2 * _TICKET_WORDS]: family 0 = forward statistics, 1 = backward statistics
+
+
+def _dev_index(device) -> int:
+    idx = torch.device(device).index
+    return torch.cuda.current_device() if idx is None else idx
+
+
+def ticket_arena(device) -> torch.Tensor:
+    """The device's arrival-ticket words (all zero between launches: the last-arriving block of a ticketed launch resets its word).
+    Launches that use them are ordered by the stream they run on; the two families (forward / backward statistics) use disjoint halves.
+    Allocated on first use - which must not be inside a graph capture (the words would live in the graph's private pool): models
+    that capture call this in their constructor."""
+    idx = _dev_index(device)
+    t = _TICKETS.get(idx)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("ops.ticket_arena(device) must be called once before the first graph capture")
+        t = _TICKETS[idx] = torch.zeros(2 * _TICKET_WORDS, device=torch.device("cuda", idx), dtype=torch.int32)
+    return t
+
+
+def _tickets(device, family: int, B: int):
+    """pointer to the ticket words of `family` for a launch over B images, or None (in-launch finalize off / batch too large)"""
+    if not IN_TICKETS or B > _TICKET_WORDS:
+        return None
+    return ticket_arena(device).data_ptr() + family * _TICKET_WORDS * 4
+
+
+def reset_tickets(device) -> None:
+    """zero the arena (one fill per train step, ahead of the first ticketed launch): a launch that was aborted mid-way cannot poison
+    the following steps"""
+    if IN_TICKETS:
+        ticket_arena(device).zero_()
+
 _SIDE_STREAMS = {}
 _DEFER_JOIN = {}
 _WG_STASH = {}          # device index -> {layer pair: (x, dy, group, layers)} while a combined_pass_wgrad region is active
@@ -56,11 +99,12 @@ def release_side_streams(device) -> None:
     _SIDE_STREAMS.pop(idx, None)
     _DEFER_JOIN.pop(idx, None)
     _WG_STASH.pop(idx, None)
+    _TICKETS.pop(idx, None)          # re-created (outside any capture) by the next model's constructor
 
 
 def device_state_empty() -> bool:
     """True when no stream, flag or stashed tensor of any model is held at module level (after every model was closed)"""
-    return not _SIDE_STREAMS and not _WG_STASH and not any(_DEFER_JOIN.values())
+    return not _SIDE_STREAMS and not _WG_STASH and not any(_DEFER_JOIN.values()) and not _TICKETS
 
 
 class combined_pass_wgrad:
@@ -341,11 +385,16 @@ def packed_shapes(spec: ConvSpec):
 
 
 def _gather(x, wp, bias, y, B, H, W, C, nrows, spec, stride, pad, pm, mode, Ho, Wo, ldc, act, slope, what, pair=None,
-            in_partial=None, border_add=None, res_add=None, bst=None):
+            in_partial=None, border_add=None, res_add=None, bst=None, fin=None):
     """one uig_conv_gather launch; pair = (wp2, bias2, group_images) makes it a two-network launch; in_partial receives the
-    fused InstanceNorm statistics partials; res_add (a tensor of y's shape) is added to the output in the epilogue"""
+    fused InstanceNorm statistics partials; res_add (a tensor of y's shape) is added to the output in the epilogue;
+    fin = (stats, eps, tickets pointer or None): the statistics come out final (uig_conv_gather_fin)"""
     lib = L.lib()
-    if bst is not None:      # (x_in, stats, act, slope, partial) of the InstanceNorm backward that consumes y as its dy
+    if fin is not None and bst is None:
+        wp2, bias2, g = pair if pair is not None else (None, None, 0)
+        rc = lib.uig_conv_gather_fin(_p(x), _p(wp), _p(bias), _p(wp2), _p(bias2), g, _p(in_partial), _p(border_add), _p(res_add), _p(y), B, H, W, C, nrows,
+                                     spec.k, spec.k, stride, pad, pm, mode, Ho, Wo, ldc, ldc, act, slope, _dt(x), _p(fin[0]), fin[1], fin[2], _stream())
+    elif bst is not None:      # (x_in, stats, act, slope, partial) of the InstanceNorm backward that consumes y as its dy
         wp2, bias2, g = pair if pair is not None else (None, None, 0)
         rc = lib.uig_conv_gather_bst(_p(x), _p(wp), _p(bias), _p(wp2), _p(bias2), g, _p(in_partial), _p(border_add), _p(res_add), _p(y), B, H, W, C, nrows,
                                      spec.k, spec.k, stride, pad, pm, mode, Ho, Wo, ldc, ldc, act, slope, _dt(x),
@@ -417,7 +466,7 @@ def in_stats_fusable(spec: ConvSpec, H: int, W: int, B: int = 1, dtype: torch.dt
 
 
 def conv_forward(spec: ConvSpec, x: torch.Tensor, wp_fwd: torch.Tensor, bias: torch.Tensor | None, pair=None,
-                 want_in_stats: bool = False, mx=None) -> torch.Tensor:
+                 want_in_stats: bool = False, mx=None, in_eps: float = 1e-5) -> torch.Tensor:
     """want_in_stats: also accumulate the following InstanceNorm's (sum, sum^2) partials in the epilogue; they travel to
     ops.InstNormActFn as the attribute `_uig_in_partial` of the returned tensor.
     mx = (wq, ws[, wq2, ws2]): run the layer on the MX block-scaled fp8 kernel (x is quantised here, the output stays bf16)."""
@@ -435,15 +484,23 @@ def conv_forward(spec: ConvSpec, x: torch.Tensor, wp_fwd: torch.Tensor, bias: to
     if want_in_stats and in_stats_fusable(spec, H, W, B, x.dtype):
         nslab = Ho * Wo // 64
         part = torch.empty((B * nslab * spec.cout_store * 2,), device=x.device, dtype=torch.float32)
+    fin = None
     if mx is not None:
         xq, xs = _mx_operand(x)
         _conv3x3_mx(xq, xs, mx, bias, pair[1] if pair is not None else None, pair[2] if pair is not None else 0, y, spec.cout, pm, mode,
                     spec.act, spec.slope, part)
     else:
+        # round 4: (mean, rstd) of the following norm (eps = in_eps) come out of this launch final - except where the inference norm
+        # finalises inside its own apply launch (small batches: InstNormAct.forward -> instnorm_infer)
+        infer_fused = INFER_FUSED_IN and not torch.is_grad_enabled() and B <= INFER_FUSED_MAX_BATCH and Ho * Wo // 64 <= INFER_FUSED_MAX_PARTIALS
+        if part is not None and IN_TICKETS and not infer_fused:
+            fin = (torch.empty((B, spec.cout_store, 2), device=x.device, dtype=torch.float32), float(in_eps), _tickets(x.device, 0, B))
         _gather(x, wp_fwd, bias, y, B, H, W, C, spec.cout, spec, spec.stride, spec.pad, pm, mode, Ho, Wo, spec.cout_store,
-                spec.act, spec.slope, "uig_conv_gather(fwd)", pair, part)
+                spec.act, spec.slope, "uig_conv_gather(fwd)", pair, part, fin=fin)
     if part is not None:
         y._uig_in_partial = (part, Ho * Wo // 64)
+    if fin is not None:
+        y._uig_in_stats = (fin[0], fin[1])
     return y
 
 
@@ -468,7 +525,7 @@ def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, 
     # pad-1 reflection 3x3 on 64-wide bf16 maps (the ResBlock convs at 256x256): the persistent strip kernel folds the mirrored
     # terms itself (mirror pixels, uig_reflect3x3_dgrad_mirror) - one launch, square map or not
     mirror = (spec.kind == "conv" and spec.reflect and spec.k == 3 and spec.pad == 1 and spec.stride == 1 and REFLECT_DGRAD_DIRECT
-              and mx is None and spec.cin_p == spec.cin and not (bst is not None and FUSE_BWD_STATS)
+              and mx is None and spec.cin_p == spec.cin and not (bst is not None and FUSE_BWD_STATS and not MIRROR_BST)
               and L.lib().uig_reflect3x3_dgrad_mirror_applicable(B, Ho, Wo, Cd, spec.cin, spec.cin_p, _dt(dy)) == 1)
     # the same on the MX fp8 kernel (round 3): mirror pixels re-quantised in LDS, no bf16 border GEMM in front
     mx_mirror = (mx is not None and MX_DGRAD_MIRROR and spec.kind == "conv" and spec.reflect and spec.k == 3 and spec.pad == 1 and spec.stride == 1
@@ -507,9 +564,9 @@ def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, 
             bord = torch.empty((B, 8, H, spec.cin_p), device=dy.device, dtype=dy.dtype)
             L.check(lib.uig_reflect3x3_dgrad_border(_p(dy), _p(wp_dgrad), _p(wp2), g, _p(bord), B, Ho, Wo, Cd, spec.cin, spec.cin_p,
                                                     _dt(dy), s), "uig_reflect3x3_dgrad_border")
-        bpart = None
-        if bst is not None and FUSE_BWD_STATS and dy.dtype == torch.bfloat16 and (H * W) % 64 == 0 and spec.cin % 64 == 0 and spec.cin_p == spec.cin \
-                and tuple(bst[0].shape) == (B, H, W, spec.cin_p) and bst[0].dtype == dy.dtype and bst[0].is_contiguous():
+        bpart = gm = None
+        if bst is not None and (MIRROR_BST if mirror else FUSE_BWD_STATS) and dy.dtype == torch.bfloat16 and (H * W) % 64 == 0 and spec.cin % 64 == 0 \
+                and spec.cin_p == spec.cin and tuple(bst[0].shape) == (B, H, W, spec.cin_p) and bst[0].dtype == dy.dtype and bst[0].is_contiguous():
             bpart = torch.empty((B * (H * W // 64) * spec.cin_p * 2,), device=dy.device, dtype=torch.float32)
             bst = (bst[0], bst[1], bst[2], bst[3], bpart)
         else:
@@ -518,13 +575,21 @@ def conv_dgrad(spec: ConvSpec, dy: torch.Tensor, wp_dgrad: torch.Tensor, in_hw, 
             dq, ds = _mx_operand(dy)
             _conv3x3_mx(dq, ds, mx, None, None, pair[2] if pair is not None else 0, dx, spec.cin, L.PAD_ZERO, L.GATHER_TRANSPOSED,
                         L.ACT_NONE, 0.0, None, bord, res_add, bst)
+        elif mirror and bst is not None:
+            # round 4: the launch also emits - final - the statistics of the InstanceNorm backward that consumes dx
+            gm = torch.empty((B, spec.cin_p, 2), device=dy.device, dtype=torch.float32)
+            L.check(lib.uig_reflect3x3_dgrad_mirror_bst(_p(dy), _p(wp_dgrad), _p(wp2), g, _p(res_add), _p(dx), B, Ho, Wo, Cd, spec.cin, spec.cin_p, _dt(dy),
+                                                        _p(bst[0]), _p(bst[1]), bst[2], bst[3], _p(bpart), _p(gm), _tickets(dy.device, 1, B), s),
+                    "uig_reflect3x3_dgrad_mirror_bst")
         elif mirror:
             L.check(lib.uig_reflect3x3_dgrad_mirror(_p(dy), _p(wp_dgrad), _p(wp2), g, _p(res_add), _p(dx), B, Ho, Wo, Cd, spec.cin, spec.cin_p,
                                                     _dt(dy), s), "uig_reflect3x3_dgrad_mirror")
         else:
             _gather(dy, wp_dgrad, None, dx, B, Ho, Wo, Cd, spec.cin, spec, 1, 1, L.PAD_ZERO, L.GATHER_TRANSPOSED, H, W, spec.cin_p,
                     L.ACT_NONE, 0.0, "uig_conv_gather(dgrad+border)", pair, None, bord, res_add, bst)
-        if bpart is not None:
+        if gm is not None:
+            dx._uig_bst_gm = gm
+        elif bpart is not None:
             dx._uig_bst_partial = (bpart, H * W // 64)
         return dx
     if spec.reflect:             # gradient w.r.t. the reflection-padded input, then fold the border back
@@ -788,7 +853,7 @@ class ConvFn(Function):
     def forward(ctx, x, weight, bias, layer, skip_link=None):
         spec = layer.spec
         mx = (layer.wq_fwd, layer.ws_fwd) if layer.mx_active(x.shape[0], x.shape[1], x.shape[2]) else None
-        y = conv_forward(spec, x, layer.wp_fwd, bias, want_in_stats=layer.emit_in_stats, mx=mx)
+        y = conv_forward(spec, x, layer.wp_fwd, bias, want_in_stats=layer.emit_in_stats, mx=mx, in_eps=layer.in_eps)
         ctx.layer, ctx.in_hw, ctx.skip_link = layer, (x.shape[1], x.shape[2]), skip_link
         ctx.bst = getattr(x, "_uig_bst", None)      # x is the output of an InstanceNorm: (its input, its stats, act, slope)
         ctx.save_for_backward(x, y if spec.act != L.ACT_NONE else None)
@@ -810,7 +875,7 @@ class PairConvFn(Function):
         mx = None
         if layer1.mx_active(x.shape[0], x.shape[1], x.shape[2]) and layer2.mx_active(x.shape[0], x.shape[1], x.shape[2]):
             mx = (layer1.wq_fwd, layer1.ws_fwd, layer2.wq_fwd, layer2.ws_fwd)
-        y = conv_forward(spec, x, layer1.wp_fwd, b1, pair=(layer2.wp_fwd, b2, group), want_in_stats=layer1.emit_in_stats, mx=mx)
+        y = conv_forward(spec, x, layer1.wp_fwd, b1, pair=(layer2.wp_fwd, b2, group), want_in_stats=layer1.emit_in_stats, mx=mx, in_eps=layer1.in_eps)
         ctx.layers, ctx.group, ctx.in_hw, ctx.skip_link = (layer1, layer2), group, (x.shape[1], x.shape[2]), skip_link
         ctx.bst = getattr(x, "_uig_bst", None)
         ctx.save_for_backward(x, y if spec.act != L.ACT_NONE else None)
@@ -881,8 +946,27 @@ class InstNormActFn(Function):
         stats = torch.empty((B, C, 2), device=x.device, dtype=torch.float32)
         y = torch.empty_like(x)
         pre = getattr(x, "_uig_in_partial", None)
+        fin = getattr(x, "_uig_in_stats", None)      # (stats, eps): already final, out of the convolution launch (round 4)
+        if fin is not None and not (tuple(fin[0].shape) == (B, C, 2) and fin[1] == float(eps)):
+            fin = None
         ctx.mx_bwd = bool(mx_bwd) and x.dtype == torch.bfloat16 and C % 32 == 0
-        if mx_fwd and x.dtype == torch.bfloat16 and C % 32 == 0:
+        want_mx = bool(mx_fwd) and x.dtype == torch.bfloat16 and C % 32 == 0
+        have_pre = pre is not None and pre[0].numel() == B * pre[1] * C * 2
+        if fin is not None or (IN_TICKETS and not have_pre and B <= _TICKET_WORDS):
+            q = s = None
+            if want_mx:
+                q = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+                s = torch.empty((B, H, W, C // 32), device=x.device, dtype=torch.uint8)
+            if fin is not None:
+                stats = fin[0]
+                L.check(lib.uig_instnorm_apply_fwd(_p(x), _p(residual), _p(y), _p(stats), _p(q), _p(s), B, H * W, C, act, slope, _dt(x), _stream()),
+                        "uig_instnorm_apply_fwd")
+            else:      # this norm's own statistics pass, finalising itself: two launches
+                L.check(lib.uig_instnorm_act_fwd_t(_p(x), _p(residual), _p(y), _p(stats), _p(ws), _tickets(x.device, 0, B), _p(q), _p(s),
+                                                   B, H * W, C, eps, act, slope, _dt(x), _stream()), "uig_instnorm_act_fwd_t")
+            if want_mx:
+                y._uig_mx = (q, s)
+        elif mx_fwd and x.dtype == torch.bfloat16 and C % 32 == 0:
             q = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
             s = torch.empty((B, H, W, C // 32), device=x.device, dtype=torch.uint8)
             have = pre is not None and pre[0].numel() == B * pre[1] * C * 2
@@ -897,7 +981,7 @@ class InstNormActFn(Function):
                                              _dt(x), _stream()), "uig_instnorm_act_fwd")
         ctx.act, ctx.slope, ctx.has_res, ctx.skip_link = act, slope, residual is not None, skip_link
         ctx.save_for_backward(x, stats)
-        if FUSE_BWD_STATS and ctx.needs_input_grad[0]:
+        if (FUSE_BWD_STATS or MIRROR_BST) and ctx.needs_input_grad[0]:
             # the convolution that consumes y produces this norm's dy in its input-gradient launch: hand it what that launch needs
             # to emit this norm's backward statistics from its epilogue (conv_dgrad / StripDesc::bst_*)
             y._uig_bst = (x, stats, act, slope)
@@ -926,7 +1010,22 @@ def instnorm_backward(dy, x, stats, act, slope, emit_mx=False):
     slabs = int(lib.uig_instnorm_bwd_colsum_slabs(B, H * W, C, _dt(x)))
     cpart = torch.empty((slabs * C * 2,), device=x.device, dtype=torch.float32)
     pre = getattr(dy, "_uig_bst_partial", None)
-    if pre is not None and pre[0].numel() == B * pre[1] * C * 2:      # statistics already produced by the launch that wrote dy
+    gm = getattr(dy, "_uig_bst_gm", None)
+    if gm is not None and tuple(gm.shape) != (B, C, 2):
+        gm = None
+    if gm is not None or (IN_TICKETS and pre is None and B <= _TICKET_WORDS):
+        # round 4: (mean g, mean g*xhat) final out of the launch that wrote dy -> the apply launch alone; else this norm's own statistics
+        # pass finalises itself (two launches instead of three)
+        q = s = None
+        if emit_mx:
+            q = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+            s = torch.empty((B, H, W, C // 32), device=x.device, dtype=torch.uint8)
+        L.check(lib.uig_instnorm_act_bwd_colsum_t(_p(dy), _p(x), _p(stats), _p(dx), _p(ws), _p(cpart), None, 0, _p(gm),
+                                                  None if gm is not None else _tickets(x.device, 1, B), _p(q), _p(s),
+                                                  B, H * W, C, act, slope, _dt(x), _stream()), "uig_instnorm_act_bwd_colsum_t")
+        if emit_mx:
+            dx._uig_mx = (q, s)
+    elif pre is not None and pre[0].numel() == B * pre[1] * C * 2:      # statistics already produced by the launch that wrote dy
         q = s = None
         if emit_mx:
             q = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
