@@ -190,26 +190,31 @@ def test_train_step_config5_b8_256_fp8_graph_vs_same_rounding_oracle():
     operands is what test_conv3x3_mx_fp8_forward_and_dgrad_vs_emulation pins (2e-3 of max), at this configuration's launch size
     (32 images) too."""
     u, ops, networks = _mods()
-    from oracle.lowprec_oracle import LowPrecOracle
+    import _step_golden as SG
+    from oracle.torch_oracle import CycleGANOracle
+    # round 4: the emulation's step is the committed fixture tests/golden/step_config5_b8_256_fp8.npz (tests/golden/make_step_golden.py);
+    # weights and inputs are regenerated from the seed and checked against its checksums; tensors on its strided 64 K-element samples
+    gold = SG.load("step_config5_b8_256_fp8.npz")
     torch.manual_seed(4)
-    o = LowPrecOracle(n_blocks=9, fp8=True)
+    o = CycleGANOracle(n_blocks=9)                      # the emulation's weights (same constructor, same seed); no oracle step runs here
     m = u.CycleGAN(n_blocks=9, dtype=torch.bfloat16, fp8=True, use_graph=True)
     m.load_state_dicts(o.G_A.state_dict(), o.G_B.state_dict(), o.D_A.state_dict(), o.D_B.state_dict())
     rA, rB = torch.rand(8, 3, 256, 256) * 2 - 1, torch.rand(8, 3, 256, 256) * 2 - 1
+    SG.assert_same_problem(gold, o, rA, rB)
     assert m.G_A[10].b[1].mx_active(32, 64, 64) and m.G_A[10].b[5].mx_active(16, 64, 64)
     lm = m.train_step(rA.cuda(), rB.cuda())
     assert m.graph_active, "the step fell back to eager launches"
-    lo = o.train_step(rA, rB)
+    lo = SG.losses(gold, "loss_emu_step0")
     print({k: (round(lo[k], 4), round(lm[k], 4)) for k in lo})
-    fb, ref = ops.from_nhwc(m.last_fake_B, 3).cpu(), o.last["fake_B"]
+    fb, ref = SG.sample(ops.from_nhwc(m.last_fake_B, 3)), torch.from_numpy(gold["fake_B_emu"])
     d = (fb - ref).abs()
     rel_fb = float((fb - ref).norm() / ref.norm())
-    print("fake_B vs emulation: L-inf", float(d.max()), "mean", float(d.mean()), "relative L2", rel_fb)
+    print("fake_B vs emulation (64 K-element sample): L-inf", float(d.max()), "mean", float(d.mean()), "relative L2", rel_fb)
     rels = {}
-    for name, mine, theirs in (("G_A ResBlock 5 conv 2 (fp8)", m.G_A[14].b[5].weight.grad, o.G_A[14].b[5].weight.grad),
-                               ("G_B up1", m.G_B[19].weight.grad, o.G_B[19].weight.grad),
-                               ("D_A 256->512", m.D_A[8].weight.grad, o.D_A[8].weight.grad)):
-        rels[name] = (float((mine.cpu() - theirs).norm() / theirs.norm()), float(F.cosine_similarity(mine.cpu().flatten(), theirs.flatten(), dim=0)))
+    for name, mine, key in (("G_A ResBlock 5 conv 2 (fp8)", m.G_A[14].b[5].weight.grad, "grad_emu_G_A.14.b.5"),
+                            ("G_B up1", m.G_B[19].weight.grad, "grad_emu_G_B.19"),
+                            ("D_A 256->512", m.D_A[8].weight.grad, "grad_emu_D_A.8")):
+        rels[name] = SG.rel_cos(mine, gold[key])
         print(f"weight gradient {name}: relative L2 vs emulation {rels[name][0]:.3e}, cosine {rels[name][1]:.4f}")
     for k in lo:
         assert lm[k] == lm[k] and abs(lo[k] - lm[k]) <= TOL_LOSS * max(1.0, abs(lo[k])), (k, lo[k], lm[k])
