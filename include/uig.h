@@ -86,6 +86,19 @@ size_t uig_conv2d_fwd_workspace_bytes(int B, int Cin, int H, int W, int Cout, in
 int uig_conv2d_fwd(const void* x, const float* w, const float* bias, void* y,
                    int B, int Cin, int H, int W, int Cout, int kH, int kW, int stride, int pad, int pad_mode, int dtype,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* The other two operators on the same contiguous-NCHW boundary (round 4).
+ * aten::convolution, transposed: ConvTranspose2d(kernel 3, stride 2, padding 1, output_padding 1) - the up-sampling layers of the path.
+ *   x (B,Cin,H,W) dtype; w (Cin,Cout,3,3) fp32; bias fp32[Cout] or NULL; y (B,Cout,2H,2W) dtype. */
+size_t uig_conv_transpose2d_fwd_workspace_bytes(int B, int Cin, int H, int W, int Cout, int dtype);
+int uig_conv_transpose2d_fwd(const void* x, const float* w, const float* bias, void* y, int B, int Cin, int H, int W, int Cout, int dtype,
+                             void* workspace, size_t workspace_bytes, void* stream);
+/* aten::convolution_backward for Conv2d (groups 1, dilation 1, stride 1 or 2); output_mask = which of dx / dW / db are non-NULL.
+ *   dy (B,Cout,Ho,Wo), x (B,Cin,H,W) dtype; w (Cout,Cin,kH,kW) fp32; dx (B,Cin,H,W) dtype; dW (Cout,Cin,kH,kW) fp32; db fp32[Cout].
+ * pad_mode UIG_PAD_REFLECT: the gradient of ReflectionPad2d(pad) + Conv2d(padding 0), folded back onto the H x W input. */
+size_t uig_conv2d_bwd_workspace_bytes(int B, int Cin, int H, int W, int Cout, int kH, int kW, int stride, int pad, int dtype);
+int uig_conv2d_bwd(const void* dy, const void* x, const float* w, void* dx, float* dW, float* db,
+                   int B, int Cin, int H, int W, int Cout, int kH, int kW, int stride, int pad, int pad_mode, int dtype,
+                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* Paired launch: the same convolution for TWO networks of identical architecture in one grid (CycleGAN's G_A/G_B and
  * D_A/D_B always process same-shaped batches).  Images b < group_images use (wp, bias), the others (wp2, bias2). */

@@ -169,6 +169,51 @@ def test_fused_mx_quantisation_equals_standalone_quantiser():
     mf.close(); ms.close()
 
 
+@pytest.mark.parametrize("H,C,B,group,res", [(8, 128, 3, 0, True), (8, 384, 4, 2, False), (32, 128, 5, 2, True), (32, 384, 2, 0, False), (128, 128, 2, 1, True),
+                                              (128, 256, 1, 0, False), (12, 256, 6, 3, True)],
+                         ids=["h8-c128", "h8-c384-pair", "h32-c128-pair", "h32-c384", "h128-c128-pair", "h128-c256", "h12-3tiles-pair"])
+def test_mx_fp8_dgrad_mirror_every_admitted_shape_class(H, C, B, group, res):
+    """uig_conv3x3_mx_fp8_dgrad_mirror_applicable admits any 64-pixel-wide map of >= 8 lines in whole 4-line tiles and any
+    128-multiple of channels, while the operator test runs 64 x 64 x 256 with a residual only.  The one-launch reflect-pad input gradient
+    (mirror pixels de-quantised, summed and RE-QUANTISED in LDS) on the other classes the rule admits: two-tile maps (H = 8: both tiles
+    are edge tiles), three tiles (one interior), non-square maps (H = 32, 128), a single K chunk (C = 128) and three (C = 384), with and
+    without the skip gradient, one and two weight sets - against the same-rounding emulation (oracle/mx_fp8.py), 1.6e-2 of max overall
+    and on the mirrored ring (lines 1 / H-2, columns 1 / W-2) separately."""
+    u, ops, networks = _mods()
+    from oracle import mx_fp8 as M
+    lib, dt = u.lib.lib(), torch.bfloat16
+    W = 64
+    assert lib.uig_conv3x3_mx_fp8_dgrad_mirror_applicable(B, H, W, C, C) == 1
+    torch.manual_seed(H * 1000 + C + B)
+    g = group if group else B
+    ls = [networks.ConvLayer("conv", C, C, 3, 1, 1, "reflect", dtype=dt, device="cuda") for _ in range(2 if group else 1)]
+    ws = [torch.randn(C, C, 3, 3) * 0.04 for _ in ls]
+    for l, w in zip(ls, ws):
+        with torch.no_grad():
+            l.weight.copy_(w)
+        l.enable_fp8(); l.ensure_packed()
+        assert l.mx_active(B, H, W)
+    dy = torch.randn(B, C, H, W) * 0.5 * torch.logspace(-0.5, 0.5, C).view(1, C, 1, 1)
+    rs = torch.randn(B, C, H, W) * 0.5
+    bf = lambda t: t.to(dt).float()
+    dyp = ops.to_nhwc(dy.cuda(), dt)
+    mx = sum(((l.wq_dgrad, l.ws_dgrad) for l in ls), ())
+    pair = (ls[1].wp_dgrad, None, g) if group else None
+    assert ops.MX_DGRAD_MIRROR
+    dx = ops.conv_dgrad(ls[0].spec, dyp, ls[0].wp_dgrad, (H, W), pair, ops.to_nhwc(rs.cuda(), dt) if res else None, mx=mx)
+    got = ops.from_nhwc(dx, C).cpu()
+    parts = [(0, g, 0)] + ([(g, B, 1)] if group else [])
+    ref = torch.cat([M.conv3x3_mx_dgrad_reflect_mirror(bf(dy[a:e]), ws[i]) for a, e, i in parts])
+    if res:
+        ref = ref + bf(rs)
+    sc = float(ref.abs().max())
+    err = (got - ref).abs()
+    ring = torch.zeros(H, W, dtype=torch.bool)
+    ring[1] = ring[H - 2] = True; ring[:, 1] = ring[:, W - 2] = True
+    print(f"H={H} C={C} B={B}: max err {float(err.max()) / sc:.2e} of max, on the mirrored ring {float(err[:, :, ring].max()) / sc:.2e}")
+    assert float(err.max()) <= 1.6e-2 * sc and float(err[:, :, ring].max()) <= 1.6e-2 * sc
+
+
 TOL_LOSS, TOL_FB_MEAN, TOL_FB_REL, TOL_GRAD, TOL_GRAD_COS = 5e-3, 0.06, 0.15, 0.85, 0.65
 
 

@@ -594,29 +594,6 @@ def test_two_rank_data_parallel_step_equals_full_batch(graph, staged, tmp_path):
         assert float(d.mean()) <= 2e-6 and float(d.max()) <= 5e-4, (k, float(d.mean()), float(d.max()))
 
 
-def test_graph_step_with_rccl_exchange_world1_and_close():
-    """Guards two aborts seen in round 1 (graph capture with a live process group; process exit with graphs + RCCL alive).
-    One worker process = one rank, as in production (the process group lives as long as the process):
-    init_process_group('nccl', world_size=1), CycleGAN(use_graph=True, force_exchange=True) so that the RCCL all-reduces
-    really run between the graph replays; 3 steps bitwise equal to the model without exchange (a 1-rank sum is the identity);
-    then the ordered teardown - CycleGAN.close(), destroy_process_group() - and a NORMAL interpreter exit whose status is
-    checked here (tests/_rccl_world1_worker.py).  A separate process because a process group created and destroyed in the
-    middle of this pytest session made the first graph replay of a LATER test crash inside the HIP runtime (seen twice,
-    deterministic; never in a process whose group lives until exit)."""
-    import subprocess
-    import sys
-    if os.environ.get("UIG_TEST_PG_INPROCESS") == "1":      # diagnostic: the round-2 arrangement (group created and destroyed inside the pytest process)
-        import importlib
-        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-        importlib.import_module("_rccl_world1_worker").main()
-        return
-    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rccl_world1_worker.py")
-    r = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=600)
-    print(r.stdout[-2000:]); print(r.stderr[-3000:])
-    assert r.returncode == 0, f"worker exit status {r.returncode}"
-    assert "RCCL_WORLD1_OK" in r.stdout
-
-
 def test_process_group_lifecycle_then_new_graph_model():
     """Round 2 saw `Fatal Python error: Segmentation fault` inside CUDAGraph.replay: the first graph replay of a freshly captured
     model after an in-process init_process_group('nccl') ... CycleGAN.close() ... destroy_process_group().  The whole sequence -
@@ -672,3 +649,42 @@ def test_generator_hypothesis_odd_shapes_fp32():
     run()
     print("hypothesis shapes:", seen)
     assert len(seen) >= 10 and any(h % 4 or w % 4 for _, h, w in seen)
+
+
+def test_graph_step_with_rccl_exchange_world1_and_close():
+    """Guards two aborts seen in round 1 (graph capture with a live process group; process exit with graphs + RCCL alive) and is the
+    standing probe for round 2's fault (`Segmentation fault` inside CUDAGraph.replay: the first replay of a fresh model after an
+    in-process init_process_group('nccl') ... CycleGAN.close() ... destroy_process_group()).
+    init_process_group('nccl', world_size=1), CycleGAN(use_graph=True, force_exchange=True) - default and staged form - so that the
+    RCCL all-reduces really run between the graph replays; 3 steps bitwise equal to the model without exchange (a 1-rank sum is the
+    identity); then the ordered teardown - CycleGAN.close(), destroy_process_group().
+    Round 4: IN THIS PROCESS by default (the round-2 arrangement: the group is created and destroyed inside the pytest session and
+    every later test file captures and replays graphs behind it), faulthandler on, placed last in this file.  Round 3 removed what is
+    believed to have caused the fault (tensors of the graphs' private memory pool outliving their graphs: DESIGN.md §4) and three
+    runs of this arrangement were clean; if it ever faults again the native frames of THAT run are the evidence to work from.
+    UIG_TEST_PG_WORKER=1: the round-2/3 fallback (one worker process = one rank whose group lives until the process exits; its exit
+    status is checked: tests/_rccl_world1_worker.py)."""
+    import faulthandler
+    import subprocess
+    import sys
+    if os.environ.get("UIG_TEST_PG_WORKER") == "1":
+        worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rccl_world1_worker.py")
+        r = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=600)
+        print(r.stdout[-2000:]); print(r.stderr[-3000:])
+        assert r.returncode == 0, f"worker exit status {r.returncode}"
+        assert "RCCL_WORLD1_OK" in r.stdout
+        return
+    import importlib
+    import torch.distributed as dist
+    faulthandler.enable(all_threads=True)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    importlib.import_module("_rccl_world1_worker").main()
+    assert not dist.is_initialized()
+    import unpaired_image_generation_amd as u
+    # a NEW graph model right behind the teardown, in this process: capture + three replays
+    torch.manual_seed(2)
+    rA, rB = (torch.rand(2, 3, 64, 64, device="cuda") * 2 - 1 for _ in range(2))
+    m = u.CycleGAN(n_blocks=3, dtype=torch.bfloat16, use_graph=True)
+    ls = [m.train_step(rA, rB) for _ in range(3)]
+    assert m.graph_active and all(v == v for l in ls for v in l.values())
+    m.close()

@@ -843,6 +843,76 @@ def test_conv2d_fwd_nchw_boundary(case, dtype):
     assert lib.uig_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, cin, H, W, cout, k, k, s, p, 0, dt, ws.data_ptr(), 16, None) < 0
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 19, 30, 26, 37, 3, 1, 1, "reflect"), (1, 3, 40, 64, 64, 7, 1, 3, "reflect"), (2, 64, 33, 40, 128, 3, 2, 1, "zero"), (3, 128, 16, 64, 256, 3, 1, 1, "reflect"),
+                                  (2, 64, 17, 20, 192, 4, 2, 1, "zero")],
+                         ids=["odd-channels-reflect", "stem7x7", "stride2", "resblock-shape", "patchgan-k4"])
+def test_conv2d_bwd_nchw_boundary(case, dtype):
+    """SURVEY §8(b), round 4: aten::convolution_backward for Conv2d on the contiguous-NCHW C boundary (uig_conv2d_bwd: repacks, the
+    input-gradient gather (+ reflection fold), split-K weight gradient + reduce and the bias column sum inside the call) against
+    F.conv2d autograd on the CPU: dx, dW, db; and the output-mask forms (dx only / dW + db only)."""
+    u, ops, networks = _mods()
+    B, cin, H, W, cout, k, s_, p, pm = case
+    torch.manual_seed(41)
+    x = torch.randn(B, cin, H, W) * 0.8
+    w = torch.randn(cout, cin, k, k) * 0.05
+    Ho, Wo = Wo_of(H, k, s_, p), Wo_of(W, k, s_, p)
+    dy = torch.randn(B, cout, Ho, Wo) * 0.5
+    rd = (lambda t: _bf(t)) if dtype == torch.bfloat16 else (lambda t: t)
+    xr, wr = rd(x).requires_grad_(True), rd(w).requires_grad_(True)
+    br = torch.zeros(cout, requires_grad=True)
+    xin = F.pad(xr, (p,) * 4, mode="reflect") if pm == "reflect" else xr
+    F.conv2d(xin, wr, br, stride=s_, padding=0 if pm == "reflect" else p).backward(rd(dy))
+    lib = u.lib.lib()
+    dt = u.lib.BF16 if dtype == torch.bfloat16 else u.lib.F32
+    n = int(lib.uig_conv2d_bwd_workspace_bytes(B, cin, H, W, cout, k, k, s_, p, dt))
+    ws = torch.empty(n, device="cuda", dtype=torch.uint8)
+    xd, dyd, wd = x.cuda().to(dtype).contiguous(), dy.cuda().to(dtype).contiguous(), w.cuda().contiguous()
+    dx = torch.full((B, cin, H, W), float("nan"), device="cuda", dtype=dtype)
+    dW = torch.full((cout, cin, k, k), float("nan"), device="cuda")
+    db = torch.full((cout,), float("nan"), device="cuda")
+    PM = u.lib.PAD_REFLECT if pm == "reflect" else u.lib.PAD_ZERO
+    st = torch.cuda.current_stream().cuda_stream
+    u.lib.check(lib.uig_conv2d_bwd(dyd.data_ptr(), xd.data_ptr(), wd.data_ptr(), dx.data_ptr(), dW.data_ptr(), db.data_ptr(), B, cin, H, W, cout, k, k, s_, p, PM, dt,
+                                   ws.data_ptr(), n, st), "uig_conv2d_bwd")
+    assert (dx.float().cpu() - xr.grad).abs().max() <= _tol(dtype, xr.grad)
+    assert (dW.cpu() - wr.grad).abs().max() <= (2e-5 if dtype == torch.float32 else 2e-3) * float(wr.grad.abs().max())      # bf16 operands, fp32 accumulate
+    assert (db.cpu() - br.grad).abs().max() <= 2e-5 * float(rd(dy).abs().sum((0, 2, 3)).max())
+    # output masks
+    dx2 = torch.empty_like(dx)
+    u.lib.check(lib.uig_conv2d_bwd(dyd.data_ptr(), None, wd.data_ptr(), dx2.data_ptr(), None, None, B, cin, H, W, cout, k, k, s_, p, PM, dt, ws.data_ptr(), n, st), "uig_conv2d_bwd")
+    assert torch.equal(dx2, dx)
+    dW2, db2 = torch.empty_like(dW), torch.empty_like(db)
+    u.lib.check(lib.uig_conv2d_bwd(dyd.data_ptr(), xd.data_ptr(), None, None, dW2.data_ptr(), db2.data_ptr(), B, cin, H, W, cout, k, k, s_, p, PM, dt, ws.data_ptr(), n, st), "uig_conv2d_bwd")
+    assert torch.equal(dW2, dW) and torch.equal(db2, db)
+    assert lib.uig_conv2d_bwd(dyd.data_ptr(), xd.data_ptr(), wd.data_ptr(), dx.data_ptr(), dW.data_ptr(), db.data_ptr(), B, cin, H, W, cout, k, k, s_, p, PM, dt, ws.data_ptr(), 16, None) < 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 256, 12, 64, 128), (1, 128, 9, 14, 64), (3, 24, 10, 6, 19)], ids=["up1-row64", "up2-odd", "odd-channels"])
+def test_conv_transpose2d_fwd_nchw_boundary(case, dtype):
+    """SURVEY §8(b), round 4: aten::convolution (transposed) for ConvTranspose2d(k3, s2, p1, output_padding 1) on the contiguous-NCHW
+    C boundary (uig_conv_transpose2d_fwd) against F.conv_transpose2d on the CPU."""
+    u, ops, networks = _mods()
+    B, cin, H, W, cout = case
+    torch.manual_seed(43)
+    x = torch.randn(B, cin, H, W)
+    w = torch.randn(cin, cout, 3, 3) * 0.05
+    b = torch.randn(cout) * 0.1
+    rd = (lambda t: _bf(t)) if dtype == torch.bfloat16 else (lambda t: t)
+    ref = F.conv_transpose2d(rd(x), rd(w), b, stride=2, padding=1, output_padding=1)
+    lib = u.lib.lib()
+    dt = u.lib.BF16 if dtype == torch.bfloat16 else u.lib.F32
+    n = int(lib.uig_conv_transpose2d_fwd_workspace_bytes(B, cin, H, W, cout, dt))
+    ws = torch.empty(n, device="cuda", dtype=torch.uint8)
+    xd, wd, bd = x.cuda().to(dtype).contiguous(), w.cuda().contiguous(), b.cuda()
+    y = torch.full((B, cout, 2 * H, 2 * W), float("nan"), device="cuda", dtype=dtype)
+    u.lib.check(lib.uig_conv_transpose2d_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, cin, H, W, cout, dt, ws.data_ptr(), n,
+                                             torch.cuda.current_stream().cuda_stream), "uig_conv_transpose2d_fwd")
+    assert (y.float().cpu() - ref).abs().max() <= _tol(dtype, ref)
+    assert lib.uig_conv_transpose2d_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, cin, H, W, cout, dt, ws.data_ptr(), 16, None) < 0
+
+
 @pytest.mark.parametrize("B,group,act", [(16, 8, "relu"), (8, 0, "none"), (3, 0, "relu")], ids=["paired16-relu", "single8-none", "small3-relu"])
 def test_instnorm_backward_statistics_from_dgrad_epilogue(B, group, act):
     """InstanceNorm -> 3x3 reflect conv (the ResBlock pattern): the norm's backward statistics (sum g, sum g*xhat) come out of the

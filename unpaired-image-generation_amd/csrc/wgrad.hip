@@ -500,6 +500,7 @@ static void pair2_generic_splits(int B1, int g1, int B2, int g2, int swap2, int 
     const long px = (long)Mh * Mw;
     const long m1 = (long)std::min(g1, B1 - g1) * px, m2 = (long)std::min(g2, B2 - g2) * px;
     long S = std::max<long>(2, std::min<long>(512 / std::max(tiles, 1), (m1 + m2) / 128));
+    if (*splits >= 2) S = *splits;      // a total the caller already sized its workspace for: keep it, divide it between the runs
     long s0 = std::max<long>(1, std::min<long>(S - 1, (S * ((long)B1 * px) + ((long)(B1 + B2) * px) / 2) / ((long)(B1 + B2) * px)));
     s0 = std::min<long>(s0, std::max<long>(1, m1 / 64));
     long s1 = std::max<long>(1, std::min<long>(S - s0, std::max<long>(1, m2 / 64)));
@@ -517,7 +518,7 @@ extern "C" int uig_wgrad_pair2_splits(int B1, int g1, int B2, int g2, int swap2,
     if (uig_wgrad_head_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype))
         return uig_wgrad_head_splits2(B1, g1, B2, g2, swap2, Mh);      // the all-rows 7x7 head kernel: an image is a block's unit, so the second pair is a pointer select
     if (dtype != UIG_BF16 && dtype != UIG_F32) return 0;
-    int splits = 0, splits0 = 0;
+    int splits = 0, splits0 = 0;      // 0: the shape's own total
     pair2_generic_splits(B1, g1, B2, g2, swap2, Mh, Mw, Np, Cq, kH, kW, dtype, &splits, &splits0);
     return splits;
 }
@@ -534,8 +535,12 @@ extern "C" int uig_wgrad_partial_pair2(const void* P, const void* Q, const void*
     if (!uig_wgrad_rows_applicable(Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, dtype, pad_mode)) {
         // generic split-K kernel: the split between the two runs is fixed by the shape, so `splits` must be the queried value
         UIG_CHECK_ARG(splits == want, "uig_wgrad_partial_pair2: splits %d != uig_wgrad_pair2_splits() = %d", splits, want);
-        int s_all = 0, s0 = 0;
+        // `splits` (== the query's answer, which does not know the pad mode: for a reflection-padded stride-2 3x3 layer with 64-pixel
+        // output rows it is the image-row kernel's count although this generic kernel runs) is what the workspace was sized for: the
+        // division between the two runs is made of THAT total, so layout and launch always agree
+        int s_all = splits, s0 = 0;
         pair2_generic_splits(B1, g1, B2, g2, swap2, Mh, Mw, Np, Cq, kH, kW, dtype, &s_all, &s0);
+        UIG_CHECK_ARG(s_all == splits && s0 >= 1 && s0 < splits, "uig_wgrad_partial_pair2: cannot divide %d splits between the two runs", splits);
         const WgRun2 r2{P2, Q2, B2, g2, swap2, s0};
         return wgrad_partial_impl(P, Q, workspace, B1, g1, Mh, Mw, Np, Hq, Wq, Cq, kH, kW, stride, pad, pad_mode, splits, dtype, stream, &r2);
     }

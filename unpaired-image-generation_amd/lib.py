@@ -39,6 +39,10 @@ SIGNATURES = {
     "uig_debug_set_mx_issuers": (None, [_i]),
     "uig_conv2d_fwd_workspace_bytes": (_sz, [_i] * 10),
     "uig_conv2d_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 11 + [_vp, _sz, _vp]),
+    "uig_conv_transpose2d_fwd_workspace_bytes": (_sz, [_i] * 6),
+    "uig_conv_transpose2d_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 6 + [_vp, _sz, _vp]),
+    "uig_conv2d_bwd_workspace_bytes": (_sz, [_i] * 10),
+    "uig_conv2d_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 11 + [_vp, _sz, _vp]),
     "uig_conv_gather": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_i, _f, _i, _vp]),
     "uig_conv_gather_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp] + [_i] * 15 + [_i, _f, _i, _vp]),
     "uig_conv_gather_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp] + [_i] * 15 + [_i, _f, _i, _vp]),

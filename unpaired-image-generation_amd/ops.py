@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import contextlib
 import os
+import threading
 
 import torch
 from torch.autograd import Function
@@ -896,17 +897,28 @@ INFER_FUSED_MAX_BATCH = int(os.environ.get("UIG_INFER_FUSED_MAX_BATCH", "2"))
 
 class small_grid_kernels:
     """Context manager (inference only): let plain 3x3 launches of very small grids (<= 64 blocks of 128x128: batch 1) run on the
-    64x64-tile strip kernel while it is active (kernel selection is process-global library state: not for concurrent use from several
-    threads).  Captured HIP graphs keep the choice made at capture time."""
+    64x64-tile strip kernel while it is active.  Kernel selection is process-global library state, so the region is serialised by a
+    lock (a second thread's Translator call waits), the previous mode is restored on exit (nesting keeps the outer choice) and a
+    train step must not run concurrently with it - the training path never selects these kernels (their statistics sum in another
+    order: the data-parallel step must equal the full-batch step).  Captured HIP graphs keep the choice made at capture time."""
 
     MODE = int(os.environ.get("UIG_INFER_SMALL_GRID", "0"))      # 0 = auto (default), 1 = wherever it applies, 2 = never (A/B)
+    _lock = threading.RLock()
+    _current = 2                                                   # the library's default: never (training keeps a batch-independent choice)
 
     def __enter__(self):
+        cls = small_grid_kernels
+        cls._lock.acquire()
+        self._prev = cls._current
+        cls._current = self.MODE
         L.lib().uig_debug_set_strip_small(self.MODE)
         return self
 
     def __exit__(self, *exc):
-        L.lib().uig_debug_set_strip_small(2)
+        cls = small_grid_kernels
+        cls._current = self._prev
+        L.lib().uig_debug_set_strip_small(self._prev)
+        cls._lock.release()
         return False
 
 
