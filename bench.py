@@ -218,6 +218,7 @@ def main():
             out["roofline"]["in_step_frac"] = fam["frac"]
             out["strip_family"] = fam
         out["g_fwd"] = generator_forward_mfma(u, torch, model, dev, dtype, B, S)
+        out["g_fwd"]["breakdown_ms"] = generator_forward_breakdown(u, torch, model, dev, dtype, B, S)
     # ordered teardown owned by the product (CycleGAN.close: drain, drop graphs / packers / streams, drain) before the other
     # configurations build their own models
     model.close()
@@ -345,6 +346,50 @@ def generator_forward_mfma(u, torch, model, dev, dtype, B, S):
     return {"what": f"paired G_A||G_B forward over {4 * B} images {S}x{S} (the step's fake+identity pass), one HIP graph",
             "ms": round(ms, 4), "tflops": round(flops / (ms * 1e-3) / 1e12, 1), "mfma_frac": round(flops / (ms * 1e-3) / peak, 4),
             "flops": flops, "target_mfma_frac": 0.40}
+
+
+def generator_forward_breakdown(u, torch, model, dev, dtype, B, S, reps=5):
+    """Where the paired generator forward's time goes, by operator family: the same 4B-image pass launched eagerly with a HIP event
+    in front of and behind every convolution launch and every InstanceNorm (statistics finalize + apply), averaged over `reps` passes.
+    Eager launches leave gaps the graph replay does not have, so the families are reported as measured AND the graph time beside
+    them (`g_fwd.ms`); their ratios are what the breakdown is for."""
+    from unpaired_image_generation_amd import ops, networks
+    from unpaired_image_generation_amd.networks import pair_forward_phys
+    x = (torch.rand(4 * B, S, S, 8, device=dev) * 2 - 1).to(dtype)
+    x[..., 3:] = 0
+    marks = []                                              # (family, start event, end event)
+    real_conv, real_norm = ops.conv_forward, networks.InstNormAct.forward
+
+    def ev():
+        e = torch.cuda.Event(enable_timing=True); e.record(); return e
+
+    def conv_forward(spec, *a, **k):
+        fam = "stem_head_7x7" if spec.k == 7 else ("resblock_conv3x3" if (spec.kind == "conv" and spec.stride == 1) else "stride2_down_up")
+        e0 = ev(); y = real_conv(spec, *a, **k); marks.append((fam, e0, ev()))
+        return y
+
+    def norm_forward(self_, xx, residual=None, skip_link=None):
+        e0 = ev(); y = real_norm(self_, xx, residual, skip_link); marks.append(("instnorm", e0, ev()))
+        return y
+
+    ops.conv_forward, networks.InstNormAct.forward = conv_forward, norm_forward
+    try:
+        with torch.no_grad():
+            pair_forward_phys(model.G_A, model.G_B, x)      # warm
+            marks.clear()
+            t0 = ev()
+            for _ in range(reps):
+                pair_forward_phys(model.G_A, model.G_B, x)
+            t1 = ev()
+        torch.cuda.synchronize(dev)
+    finally:
+        ops.conv_forward, networks.InstNormAct.forward = real_conv, real_norm
+    out = {}
+    for fam, e0, e1 in marks:
+        out[fam] = out.get(fam, 0.0) + e0.elapsed_time(e1) / reps
+    out = {k: round(v, 4) for k, v in out.items()}
+    out["eager_total"] = round(t0.elapsed_time(t1) / reps, 4)
+    return out
 
 
 def dominant_kernel_roofline(u, torch, dev, dtype, nimg, hw, iters, fp8=False):

@@ -372,6 +372,18 @@ int uig_instnorm_act_bwd_colsum_t(const void* dy, const void* x, const float* st
                                   float* colsum_partial, const float* pre_partial, int pre_nslab, const float* pre_gm,
                                   unsigned* tickets, void* mx_q, void* mx_s,
                                   int B, int64_t HW, int C, int act, float slope, int dtype, void* stream);
+/* Round 4: the whole InstanceNorm backward in ONE launch and ONE pass over dy and x (statistics, finalize and apply fused; the blocks
+ * of an image synchronise inside the kernel through arrival counters and keep their pixels in registers across the waits): replaces the
+ * three launches of uig_instnorm_act_bwd_colsum.  uig_instnorm_bwd_fused_applicable -> NB (blocks = column-sum slabs per image) or 0
+ * (shape too large for the whole grid to be resident at once: use the three-launch form).  partial fp32[B][NB][C][2], gm fp32[B][C][2]:
+ * scratch; colsum_partial fp32[B][NB][C][2]; sync: >= 4*B zero 32-bit words, left zero; err: one word set to 1 if a bounded in-kernel
+ * wait ran out (results invalid; never a hang).  Same arithmetic as the three-launch form; the statistics' fp32 partial sums cover other
+ * pixel ranges, so results agree to rounding, not bitwise.  uig_debug_set_in_fused(0): the query answers 0 (A/B hook). */
+void uig_debug_set_in_fused(int on);
+int uig_instnorm_bwd_fused_applicable(int B, int64_t HW, int C, int dtype);
+int uig_instnorm_act_bwd_fused(const void* dy, const void* x, const float* stats, void* dx, float* partial, float* gm,
+                               float* colsum_partial, unsigned* sync, unsigned* err, void* mx_q, void* mx_s,
+                               int B, int64_t HW, int C, int act, float slope, int dtype, void* stream);
 int uig_bias_grad_from_partials(const float* colsum_partial, float* db, int nslab_total, int C, int Nreal,
                                 int accumulate, void* stream);
 

@@ -2,9 +2,10 @@
 last-arriving block reduces the slabs in the finalize kernel's fixed order; include/uig.h, uig_conv_gather_fin) and the norm-backward
 statistics carried by the mirror-pixel input-gradient launch (uig_reflect3x3_dgrad_mirror_bst).
 
-Both are OPT-IN (UIG_IN_TICKETS=1 / UIG_MIRROR_BST=1): measured on MI355X they lose to the launches they remove (the
-last arriver's cold 128-KB slab read costs 7-14 us per convolution launch against 3.7 us for the finalize launch; the norm's input
-arrives in 16-MB bursts when every CU enters its epilogue at once).  The tests switch them on.
+Plus the InstanceNorm backward as ONE launch (uig_instnorm_act_bwd_fused: the blocks of an image synchronise inside the kernel).
+All three are OPT-IN (UIG_IN_TICKETS=1 / UIG_MIRROR_BST=1 / UIG_FUSED_IN_BWD=1): measured on MI355X they lose to the launches they
+remove (an inter-workgroup hand-off costs ~2 us per memory round trip, ~8 us per synchronisation; a kernel boundary
+costs 4-5 us).  The tests switch them on.
 
 What is pinned here: the in-launch results are BIT-IDENTICAL to the finalize launch they replace (same slabs, same fp64 association
 order) - per operator at the benchmark's shapes, repeatedly and under memory load (an inter-workgroup hand-off that is wrong shows up
@@ -251,3 +252,88 @@ def test_train_step_mirror_bst_tracks_the_separate_statistics_pass(monkeypatch):
     # Adam's first steps move every weight by ~lr = 2e-4 whatever the gradient's size: a gradient near zero that changes sign moves its
     # weight by up to 2 lr per step; on average the two runs stay together
     assert float((w1 - w0).abs().max()) <= 1e-3 and float((w1 - w0).abs().mean()) <= 1e-4, (float((w1 - w0).abs().max()), float((w1 - w0).abs().mean()))
+
+
+@pytest.mark.parametrize("shape,act,dtype", [((16, 64, 64, 256), "relu", torch.bfloat16), ((8, 64, 64, 256), "none", torch.bfloat16), ((12, 64, 64, 256), "relu", torch.bfloat16),
+                                             ((16, 64, 64, 128), "lrelu", torch.bfloat16), ((16, 32, 32, 256), "lrelu", torch.bfloat16), ((5, 31, 31, 512), "lrelu", torch.bfloat16),
+                                             ((3, 24, 40, 64), "relu", torch.bfloat16), ((2, 32, 32, 128), "relu", torch.float32)],
+                         ids=["resblock16", "resblock8-none", "resblock12", "patchgan-128", "patchgan-256", "patchgan-512-odd", "small-64ch", "f32"])
+def test_fused_instnorm_backward_one_launch_vs_three_launch_form_and_oracle(shape, act, dtype, monkeypatch):
+    """Round 4: InstanceNorm backward as ONE launch and one pass over dy and x (uig_instnorm_act_bwd_fused: statistics, finalize and
+    apply fused; the blocks of an image synchronise inside the kernel and keep their pixels in registers across the waits).
+    Against the three-launch form: same arithmetic, the statistics' fp32 partial sums cover other pixel ranges - dx within bf16 rounding
+    (max 1e-2 of max, mean 2e-4), the bias gradient from the column-sum partials to 1e-5 of sum |dx|; against the oracle
+    (F.instance_norm autograd on the same bf16 inputs), 1.6e-2 of max; run-to-run BITWISE reproducible under memory load (the in-kernel
+    hand-offs: a stale read would show as a different result on some run); the kernel's error word stays 0."""
+    u, ops, networks = _mods()
+    B, H, W, C = shape
+    lib = u.lib.lib()
+    dt = u.lib.BF16 if dtype == torch.bfloat16 else u.lib.F32
+    assert lib.uig_instnorm_bwd_fused_applicable(B, H * W, C, dt) > 0
+    A = {"relu": u.lib.ACT_RELU, "none": u.lib.ACT_NONE, "lrelu": u.lib.ACT_LRELU}[act]
+    torch.manual_seed(9)
+    x = (torch.randn(shape, device="cuda") * 1.5 + 0.3).to(dtype)
+    dy = (torch.randn(shape, device="cuda") * 0.5).to(dtype)
+    junk = torch.empty(32 << 20, device="cuda", dtype=torch.float32)
+
+    def run(fused):
+        monkeypatch.setattr(ops, "FUSED_IN_BWD", fused)
+        xr = x.clone().requires_grad_(True)
+        xin = xr * 1.0                                      # non-leaf: its gradient tensor (with the column-sum attribute) reaches the hook
+        got = []
+        xin.register_hook(lambda t: got.append(t))
+        y = ops.InstNormActFn.apply(xin, None, A, 0.2, 1e-5)
+        y.backward(dy)
+        g = got[0]
+        db = ops._bias_grad_from_partials(g._uig_colsum, 0, B, C, None, False)
+        return g.detach().clone(), db
+
+    dx0, db0 = run(False)
+    outs = []
+    for it in range(5):
+        if it % 2:
+            junk.normal_()
+        outs.append(run(True))
+    dx1, db1 = outs[0]
+    for k, (a, b) in enumerate(outs[1:]):
+        assert torch.equal(a, dx1) and torch.equal(b, db1), f"run {k + 1} differs from run 0"
+    ops.check_sync_errors("cuda")
+    sc = float(dx0.float().abs().max())
+    d = (dx1.float() - dx0.float()).abs()
+    tol_max, tol_mean = (1e-2, 2e-4) if dtype == torch.bfloat16 else (2e-5, 2e-6)
+    assert float(d.max()) <= tol_max * sc and float(d.mean()) <= tol_mean * sc, (float(d.max()) / sc, float(d.mean()) / sc)
+    assert float((db1 - db0).abs().max()) <= 1e-5 * float(dx0.float().abs().sum((0, 1, 2)).max()) + 1e-6
+    # oracle
+    xc = x.float().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    yr = F.instance_norm(xc, eps=1e-5)
+    yr = F.relu(yr) if act == "relu" else (F.leaky_relu(yr, 0.2) if act == "lrelu" else yr)
+    yr.backward(dy.float().cpu().permute(0, 3, 1, 2))
+    ref = xc.grad.permute(0, 2, 3, 1)
+    assert float((dx1.float().cpu() - ref).abs().max()) <= (1.6e-2 if dtype == torch.bfloat16 else 2e-5) * float(ref.abs().max()) + 1e-6
+    assert int(ops.ticket_arena("cuda").abs().sum()) == 0, "synchronisation words must be zero behind the launches"
+
+
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graph"])
+def test_train_step_fused_instnorm_backward_tracks_the_three_launch_form(use_graph, monkeypatch):
+    """configs[1]'s step (9 blocks, B = 4, 256x256, bf16), two steps with the fused InstanceNorm backward (opt-in) vs the three-launch
+    form: step 0's losses are the same forward computation (bitwise), step 1's agree to 2e-3 relative, the weights stay together."""
+    u, ops, networks = _mods()
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "FUSED_IN_BWD", fused)
+        torch.manual_seed(0)
+        m = u.CycleGAN(n_blocks=9, dtype=torch.bfloat16, device="cuda", use_graph=use_graph)
+        torch.manual_seed(1)
+        rA = torch.rand(4, 3, 256, 256, device="cuda") * 2 - 1
+        rB = torch.rand(4, 3, 256, 256, device="cuda") * 2 - 1
+        ls = [m.train_step(rA, rB, sync=False).clone() for _ in range(2)]
+        torch.cuda.synchronize()
+        ops.check_sync_errors("cuda")
+        res[fused] = (torch.stack(ls).cpu(), m.grp_G.flat.clone().cpu())
+        m.close()
+        del m
+    l1, l0 = res[True][0], res[False][0]
+    assert torch.equal(l1[0, :6], l0[0, :6])
+    assert float(((l1[1] - l0[1]).abs() / l0[1].abs()).max()) <= 2e-3, (l1[1], l0[1])
+    w1, w0 = res[True][1], res[False][1]
+    assert float((w1 - w0).abs().max()) <= 1e-3 and float((w1 - w0).abs().mean()) <= 1e-4

@@ -340,6 +340,227 @@ __global__ __launch_bounds__(256) void in_apply_bwd_kernel(const T* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fused backward (round 4)
+// InstanceNorm backward in ONE launch and ONE pass over the data: statistics pass, finalize launch and apply pass (40 us for the
+// ResBlock maps of the benchmark: 13.4 + 5.3 + 21.5, reading dy and x twice) become a kernel in which every thread loads its pixels of
+// dy and x ONCE (8 pixels x 16 bytes x 2 tensors, all 16 loads in flight together), keeps them in registers across two in-kernel
+// synchronisations of the blocks that share an image, and writes dx: 67 MB read + 33 MB written per 16-image launch instead of 134 + 33.
+//   phase 1  per-thread (sum g, sum g*xhat) over its pixels, block reduce through LDS (in_stats_kernel's order), the block's partial
+//            [C][2] stored write-through (sc1);
+//   sync 1   arrival counter of the image (one relaxed agent-scope fetch_add per block, one lane polls with sc1 loads + s_sleep);
+//   finalize DISTRIBUTED: block s of the image's NB blocks reduces the NB partials of channels [s * cpb, (s + 1) * cpb) in fp64
+//            (16 slab lanes per channel, sequential sums, xor-shuffle tree: the finalize kernel's association) and stores
+//            (mean g, mean g*xhat) write-through - 2 KB read per block, not NB * C * 8;
+//   sync 2   second arrival counter; then every thread reads the 8 (mean g, mean g*xhat) pairs of its channels (sc1 loads);
+//   phase 2  dx = rstd * (g - mean g - xhat * mean g*xhat) from the registers, stored; column sums of the stored dx (COLSUM) and the
+//            MX fp8 form of dx as in in_apply_bwd_kernel; the block that DEPARTS last resets the image's three counters.
+// Residency: blocks of one image wait for each other, so the whole grid must be co-resident: the host admits the launch only when
+// grid <= CUs x (blocks per CU of this kernel) (instnorm_bwd_fused_plan) and images are laid out so that consecutive block ids cover
+// whole images eight at a time (image = xcd + 8 * (j / NB): an image's blocks share an XCD where dispatch is round-robin - speed only).
+// Every spin is BOUNDED: a block that waits longer than spin_limit polls sets *err and goes on with whatever it has (wrong numbers,
+// no hang); the host checks the word when it next synchronises (ops.check_sync_errors) and switches the fused path off.
+// Hand-off protocol as uig_common.h's UigFin (cdna_hip_programming.md Guideline 16, sc1 form): every handed-off byte is stored sc1
+// and drained before the counter add that publishes it; every load of it is an sc1 load.
+struct InFusedDesc {
+    long HW; int C, CC, NB, B, act; float slope;
+    float* partial;           // [B][NB][C][2]
+    float* gm;                // [B][C][2]
+    unsigned* sync;           // [B][4]: arrive 1, arrive 2, depart, -   (zero between launches)
+    unsigned* err;            // set to 1 when a bounded spin ran out
+    double inv_n; unsigned spin_limit; int cpb;
+};
+
+__device__ __forceinline__ bool in_fused_sync(unsigned* cnt, unsigned target, unsigned* err, unsigned limit, unsigned* lds_word, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's sc1 stores are through
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned ok = 1u, spins = 0u;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > limit) { ok = 0u; __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+        *reinterpret_cast<volatile unsigned*>(lds_word) = ok;
+    }
+    __syncthreads();
+    return *reinterpret_cast<volatile unsigned*>(lds_word) != 0u;
+}
+
+template <typename T, bool COLSUM, int ACT>
+__device__ __forceinline__ void in_bwd_fused_body(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx,
+                                                  const float* __restrict__ stats, float* __restrict__ colsum_partial,
+                                                  const InFusedDesc& d, float* red) {
+    constexpr int E = ElemTraits<T>::E, PPT = 8;
+    const int tid = threadIdx.x;
+    const int pb = blockIdx.x, xcd = pb & 7, jb = pb >> 3;
+    const int b = xcd + 8 * (jb / d.NB), slab = jb % d.NB;
+    if (b >= d.B) return;                                  // block-uniform: images past the batch (grid rounded up to eight images)
+    const int C = d.C, CC = d.CC, PL = 256 / CC, pl = tid / CC, cc = tid % CC;
+    const long sp = (d.HW + d.NB - 1) / d.NB, p0 = slab * sp, p1 = min(d.HW, p0 + sp);
+    const unsigned img_bytes = (unsigned)(d.HW * C * (long)sizeof(T));
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (long)b * d.HW * C), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dy + (long)b * d.HW * C), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dx + (long)b * d.HW * C, 0, img_bytes, 0x00020000);
+    // byte offset of this thread's pixel k inside its image, or out of the buffer's range (loads return zeros: g = 0; stores are dropped).
+    // Derived from ONE register (off0) that is made opaque again in front of phase 2: the eight offsets are recomputed there, not carried
+    // across the waits
+    int off0 = (int)(((p0 + pl) * C + cc * E) * (long)sizeof(T));
+    const int kstride = PL * C * (int)sizeof(T);
+    const int nvalid = (int)((p1 - p0 - pl + PL - 1) / PL);          // pixels k < nvalid of this thread lie inside the block's range (may be <= 0)
+    auto poff = [&](int k) -> int { return k < nvalid ? off0 + k * kstride : -1; };
+    // ---- every load of this thread, issued together
+    u32x4_t xr[PPT], gr[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int off = poff(k);
+        xr[k] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+        gr[k] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0));
+    }
+    const float slope = d.slope;
+    auto gval = [&](float g, float xh) -> float {
+        if constexpr (ACT == UIG_ACT_RELU) return xh > 0.f ? g : 0.f;
+        else if constexpr (ACT == UIG_ACT_LRELU) return xh > 0.f ? g : g * slope;
+        else return g;
+    };
+    const float* stp = stats + ((long)b * C + cc * E) * 2;
+    constexpr int EH = E / 2;
+    auto unpack_half = [&](const u32x4_t& w, int h, float (&f)[EH]) {
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int i2 = 0; i2 < EH / 2; ++i2) { const unsigned v = w[h * (EH / 2) + i2]; f[2 * i2] = __uint_as_float(v << 16); f[2 * i2 + 1] = __uint_as_float(v & 0xffff0000u); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EH; ++e) f[e] = __uint_as_float(w[h * EH + e]);
+        }
+    };
+    // ---- phase 1: partial statistics of the block's pixels (one half of the thread's channels at a time: registers)
+    {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float mu[EH], rs[EH], s1[EH], s2[EH];
+#pragma unroll
+            for (int e = 0; e < EH; ++e) { mu[e] = stp[2 * (h * EH + e)]; rs[e] = stp[2 * (h * EH + e) + 1]; s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                float xv[EH], gv[EH];
+                unpack_half(xr[k], h, xv); unpack_half(gr[k], h, gv);
+#pragma unroll
+                for (int e = 0; e < EH; ++e) {
+                    const float xh = (xv[e] - mu[e]) * rs[e];
+                    const float g = gval(gv[e], xh);
+                    s1[e] += g; s2[e] += g * xh;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EH; ++e) { red[(tid * E + h * EH + e) * 2] = s1[e]; red[(tid * E + h * EH + e) * 2 + 1] = s2[e]; }
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            float a = 0.f, q = 0.f;
+            for (int l = 0; l < PL; ++l) { a += red[(l * C + c) * 2]; q += red[(l * C + c) * 2 + 1]; }
+            uig_store8_sc1(d.partial + (((long)b * d.NB + slab) * C + c) * 2, a, q);
+        }
+    }
+    // the packed pixels stay in registers across the waits; opaque from here on: nothing derived from them in phase 1 (the unpacked
+    // values, xhat, g: 128 floats) may be carried over - phase 2 recomputes from the 64 packed registers
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) asm volatile("" : "+v"(xr[k]), "+v"(gr[k]));
+    asm volatile("" : "+v"(off0));
+    unsigned* sy = d.sync + (long)b * 4;
+    in_fused_sync(sy + 0, (unsigned)d.NB, d.err, d.spin_limit, reinterpret_cast<unsigned*>(red), tid);
+    // ---- distributed finalize: this block's share of the channels
+    {
+        const int sl = tid & 15, it = tid >> 4;
+        const int c_begin = slab * d.cpb, c_end = min(C, c_begin + d.cpb);
+        const float* pbase = d.partial + (long)b * d.NB * C * 2;
+        for (int c0 = c_begin; c0 < c_end; c0 += 16) {      // block-uniform trip count
+            const int c = min(c0 + it, c_end - 1);
+            double a = 0.0, q = 0.0;
+            for (int s_ = sl; s_ < d.NB; s_ += 16) {
+                const unsigned long long v = uig_load8_sc1(pbase + ((long)s_ * C + c) * 2);
+                a += (double)__uint_as_float((unsigned)v); q += (double)__uint_as_float((unsigned)(v >> 32));
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 16); q += __shfl_xor(q, o, 16); }
+            if (sl == 0 && c0 + it < c_end) uig_store8_sc1(d.gm + ((long)b * C + c) * 2, (float)(a * d.inv_n), (float)(q * d.inv_n));
+        }
+    }
+    in_fused_sync(sy + 1, (unsigned)d.NB, d.err, d.spin_limit, reinterpret_cast<unsigned*>(red), tid);
+    // ---- phase 2: apply from the registers, one HALF of the thread's channels at a time (its (mean, rstd, mean g, mean g*xhat) then take
+    //      16 registers instead of 32: with all eight channels the kernel spilled ~30 registers per thread - scratch traffic as large as
+    //      the data - and measured 96 us against 36 for the three launches); each half is one 8-byte (bf16) / 8-byte (f32: two channels) store
+    float cs[E];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float mu[EH], rs[EH], mg[EH], mgx[EH];
+#pragma unroll
+        for (int e = 0; e < EH; ++e) {
+            const unsigned long long v = uig_load8_sc1(d.gm + ((long)b * C + cc * E + h * EH + e) * 2);
+            mg[e] = __uint_as_float((unsigned)v); mgx[e] = __uint_as_float((unsigned)(v >> 32)); cs[h * EH + e] = 0.f;
+            mu[e] = stp[2 * (h * EH + e)]; rs[e] = stp[2 * (h * EH + e) + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int off = poff(k);
+            float xv[EH], gv[EH];
+            unpack_half(xr[k], h, xv); unpack_half(gr[k], h, gv);
+#pragma unroll
+            for (int e = 0; e < EH; ++e) {
+                const float xh = (xv[e] - mu[e]) * rs[e];
+                gv[e] = rs[e] * (gval(gv[e], xh) - mg[e] - xh * mgx[e]);
+            }
+            u32x2_t pk;
+            float rv[EH];
+            if constexpr (sizeof(T) == 2) {
+                pk[0] = (unsigned)f32_to_bf16(gv[0]) | ((unsigned)f32_to_bf16(gv[1]) << 16);
+                pk[1] = (unsigned)f32_to_bf16(gv[2]) | ((unsigned)f32_to_bf16(gv[3]) << 16);
+                rv[0] = __uint_as_float(pk[0] << 16); rv[1] = __uint_as_float(pk[0] & 0xffff0000u);
+                rv[2] = __uint_as_float(pk[1] << 16); rv[3] = __uint_as_float(pk[1] & 0xffff0000u);
+            } else {
+                pk[0] = __float_as_uint(gv[0]); pk[1] = __float_as_uint(gv[1]);
+                rv[0] = gv[0]; rv[1] = gv[1];
+            }
+            __builtin_amdgcn_raw_buffer_store_b64(pk, rd, off >= 0 ? off + h * 8 : -1, 0, 0);      // out-of-range offset: dropped
+            if constexpr (COLSUM) {
+#pragma unroll
+                for (int e = 0; e < EH; ++e) cs[h * EH + e] += off >= 0 ? rv[e] : 0.f;
+            }
+        }
+    }
+    if constexpr (COLSUM) {
+        __syncthreads();                                   // red[] carried the sync flag
+#pragma unroll
+        for (int e = 0; e < E; ++e) red[tid * E + e] = cs[e];
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            float a = 0.f;
+            for (int l = 0; l < PL; ++l) a += red[l * C + c];
+            float* out = colsum_partial + (((long)b * d.NB + slab) * C + c) * 2;
+            out[0] = a; out[1] = 0.f;
+        }
+    }
+    // ---- depart: the image's last block leaves its counters zero for the next launch
+    if (tid == 0) {
+        const unsigned dcount = __hip_atomic_fetch_add(sy + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (dcount == (unsigned)d.NB - 1u) {
+            __hip_atomic_store(sy + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sy + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sy + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+template <typename T, bool COLSUM>
+__global__ __launch_bounds__(256, 4) void in_bwd_fused_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx,
+                                                               const float* __restrict__ stats, float* __restrict__ colsum_partial,
+                                                               const InFusedDesc d) {
+    __shared__ float red[256 * ElemTraits<T>::E * 2];
+    // the activation is a launch constant: ONE branch around the whole body
+    if (d.act == UIG_ACT_RELU) in_bwd_fused_body<T, COLSUM, UIG_ACT_RELU>(dy, x, dx, stats, colsum_partial, d, red);
+    else if (d.act == UIG_ACT_LRELU) in_bwd_fused_body<T, COLSUM, UIG_ACT_LRELU>(dy, x, dx, stats, colsum_partial, d, red);
+    else in_bwd_fused_body<T, COLSUM, UIG_ACT_NONE>(dy, x, dx, stats, colsum_partial, d, red);
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static int stats_slabs(long HW, int CC) { return (int)std::max<long>(1, std::min<long>(128, HW * CC / (256 * 4))); }
 static int apply_slabs(long HW, int CC) { return (int)std::max<long>(1, std::min<long>(2048, HW * CC / (256 * 4))); }
@@ -667,4 +888,66 @@ extern "C" int uig_instnorm_act_bwd_colsum_t(const void* dy, const void* x, cons
     if (mx_q != nullptr) UIG_CHECK_ARG(dtype == UIG_BF16 && C % 32 == 0, "uig_instnorm_act_bwd_colsum_t: MX output needs bf16 and C %% 32 == 0 (C=%d)", C);
     return instnorm_bwd_impl(dy, x, stats, dx, workspace, colsum_partial, B, HW, C, act, slope, dtype, stream,
                              (unsigned char*)mx_q, (unsigned char*)mx_s, pre_partial, pre_nslab, tickets, pre_gm);
+}
+
+// ---- fused backward (round 4): plan and entry point
+static int g_in_fused = 1;      // A/B hook: 0 = uig_instnorm_bwd_fused_applicable answers 0
+extern "C" void uig_debug_set_in_fused(int on) { g_in_fused = on; }
+static int device_cus_in() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 0;
+        return v;
+    }();
+    return n;
+}
+template <typename K> static int blocks_per_cu(K kern) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, 0) != hipSuccess) n = 0;
+    return n;
+}
+// blocks per image of the fused backward for this shape, or 0 when it does not apply: 8 pixels per thread (NB = ceil(HW / (8 * pixel
+// lanes))), at most 256 blocks per image, and the WHOLE grid (images rounded up to eight) resident at once.
+extern "C" int uig_instnorm_bwd_fused_applicable(int B, int64_t HW, int C, int dtype) {
+    if (!g_in_fused || (dtype != UIG_BF16 && dtype != UIG_F32) || B <= 0 || HW <= 0 || C <= 0) return 0;
+    const int E = dtype == UIG_BF16 ? 8 : 4;
+    if (C % E != 0) return 0;
+    const int CC = C / E;
+    if (CC > 256 || 256 % CC != 0 || (long)HW * C * (dtype == UIG_BF16 ? 2 : 4) >= (1L << 31)) return 0;
+    const int PL = 256 / CC;
+    const long NB = (HW + 8L * PL - 1) / (8L * PL);
+    if (NB < 1 || NB > 256) return 0;
+    static const int occ_b = blocks_per_cu(in_bwd_fused_kernel<bf16_t, true>), occ_f = blocks_per_cu(in_bwd_fused_kernel<float, true>);
+    const long capacity = (long)device_cus_in() * (dtype == UIG_BF16 ? occ_b : occ_f);
+    const long grid = 8L * ((B + 7) / 8) * NB;
+    return grid <= capacity ? (int)NB : 0;
+}
+
+// aten::native_batch_norm_backward (+ activation backward) in one launch (see in_bwd_fused_kernel).  partial fp32[B][NB][C][2] and
+// gm fp32[B][C][2]: scratch; colsum_partial fp32[B][NB][C][2] (NB slabs per image: the bias gradient of the convolution in front);
+// sync: >= 4 * B zero-initialised 32-bit words (left zero), err: one word the kernel sets to 1 if a bounded wait ran out (results are
+// then garbage: check it at the next host synchronisation); mx_q / mx_s optional (as uig_instnorm_act_bwd_colsum_mx).
+// Only where uig_instnorm_bwd_fused_applicable(B, HW, C, dtype) = NB > 0.
+extern "C" int uig_instnorm_act_bwd_fused(const void* dy, const void* x, const float* stats, void* dx, float* partial, float* gm,
+                                          float* colsum_partial, unsigned* sync, unsigned* err, void* mx_q, void* mx_s,
+                                          int B, int64_t HW, int C, int act, float slope, int dtype, void* stream) {
+    UIG_CHECK_ARG(dy && x && stats && dx && partial && gm && colsum_partial && sync && err, "uig_instnorm_act_bwd_fused: null pointer");
+    UIG_CHECK_ARG(act == UIG_ACT_NONE || act == UIG_ACT_RELU || act == UIG_ACT_LRELU, "uig_instnorm_act_bwd_fused: bad act %d", act);
+    UIG_CHECK_ARG(mx_q == nullptr && mx_s == nullptr, "uig_instnorm_act_bwd_fused: the MX fp8 form of dx is not produced by this launch (pass NULL; use uig_instnorm_act_bwd_colsum_mx)");
+    const int NB = uig_instnorm_bwd_fused_applicable(B, HW, C, dtype);
+    UIG_CHECK_ARG(NB > 0, "uig_instnorm_act_bwd_fused: shape B=%d HW=%ld C=%d not admitted (query uig_instnorm_bwd_fused_applicable)", B, (long)HW, C);
+    InFusedDesc d{};
+    const int E = dtype == UIG_BF16 ? 8 : 4;
+    d.HW = HW; d.C = C; d.CC = C / E; d.NB = NB; d.B = B; d.act = act; d.slope = slope;
+    d.partial = partial; d.gm = gm; d.sync = sync; d.err = err; d.inv_n = 1.0 / (double)HW;
+    d.spin_limit = 4000000u;                               // ~1 s of s_sleep polls: far beyond any healthy wait (microseconds)
+    d.cpb = (C + NB - 1) / NB;
+    const dim3 grid(8 * ((B + 7) / 8) * NB);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UIG_BF16)
+        hipLaunchKernelGGL((in_bwd_fused_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, stats, colsum_partial, d);
+    else
+        hipLaunchKernelGGL((in_bwd_fused_kernel<float, true>), grid, dim3(256), 0, s, (const float*)dy, (const float*)x, (float*)dx, stats, colsum_partial, d);
+    UIG_LAUNCH_CHECK("uig_instnorm_act_bwd_fused");
+    return 0;
 }

@@ -11,10 +11,13 @@ MI355X-first choices (all result-preserving because InstanceNorm statistics are 
     kernel and the data-parallel exchange a single RCCL all-reduce per group;
   * the whole step is static-shape and sync-free, so it is captured once into HIP graphs and replayed
     (segments: G fwd+bwd | D fwd+bwd | Adam G | Adam D), with the gradient all-reduces enqueued between segments on a
-    communication stream.  Under data parallelism the backward pass of each phase is cut into stages (4 for the generators,
-    2 for the discriminators) whose slices of the flat gradient buffer are all-reduced while the next stage runs: only the
-    last, smallest bucket (the first layers: 3 MB of 91 MB for the generators) is exposed; the generator update (wait for its
-    buckets, Adam, weight repack) runs on its own stream under the discriminator phase.
+    communication stream.  Data parallel, default (round 3): ONE all-reduce per optimiser group right behind its phase - the
+    generators' runs under the whole discriminator phase, the discriminators' under the generators' Adam + weight repack, all
+    on the main stream.  Opt-in (stage_backward=True / UIG_DP_STAGED=1): the backward pass of each phase cut into stages (4 for
+    the generators, 2 for the discriminators) whose slices of the flat gradient buffer are all-reduced while the next stage runs
+    (only the last, smallest bucket - the first layers: 3 MB of 91 MB for the generators - is exposed); UIG_OVERLAP_UPDATE=1 puts
+    the generator update (wait for its buckets, Adam, weight repack) on its own stream under the discriminator phase.  Which
+    form wins at N > 1 has not been measured on hardware.
 """
 from __future__ import annotations
 
@@ -402,4 +405,5 @@ class CycleGAN:
         self.last_losses = losses
         if not sync:
             return losses
+        ops.check_sync_errors(self.device)              # the fused kernels' bounded in-kernel waits (one device word; the host synchronises here anyway)
         return dict(zip(LOSS_NAMES, self.xchg.mean_scalars(losses).tolist()))

@@ -2,10 +2,12 @@
 
 One process per GPU; replicas hold identical parameters; InstanceNorm statistics are per sample, so the only exchange
 is a sum-all-reduce of each optimiser group's flat fp32 gradient buffer per step (RCCL over xGMI when the process group's
-backend is "nccl"; gloo on CPU in the tests), issued in BUCKETS: the backward pass is cut into stages (staged_backward),
-the parameters behind each cut are one contiguous slice of the flat buffer (FlatGroup's interleaved layout), and a slice's
-all-reduce is started on the communication stream as soon as its stage has finished, so it runs under the next stage's
-kernels (run_exchange_phase).  The 1/world_size average is folded into the Adam kernel.
+backend is "nccl"; gloo on CPU in the tests).  Default (round 3): the whole buffer as ONE bucket, started on the communication
+stream right behind its phase (it runs under the next phase).  Staged form (opt-in: CycleGAN(stage_backward=True) /
+UIG_DP_STAGED=1): issued in BUCKETS - the backward pass is cut into stages (staged_backward), the parameters behind each cut are
+one contiguous slice of the flat buffer (FlatGroup's interleaved layout), and a slice's all-reduce is started as soon as its
+stage has finished, so it runs under the next stage's kernels (run_exchange_phase).  The 1/world_size average is folded into
+the Adam kernel.
 This module has no dependency on the HIP library, so its logic is covered by world_size-2 gloo tests on CPU.
 """
 from __future__ import annotations

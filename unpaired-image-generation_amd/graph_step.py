@@ -1,8 +1,10 @@
 """HIP-graph execution of the train step: the static-shape, sync-free step is captured once into graphs
-(G fwd+bwd | D fwd+bwd | Adam G + repack G | Adam D + repack D) and replayed.  Under data parallelism each phase's backward
-pass is cut into stages (cyclegan._g_stages / _d_stages) and every stage is its own graph: bucket k's all-reduce is enqueued
-on the communication stream between the replays of stage k and stage k+1 and runs under the latter; the generator update
-graph (wait for the buckets, Adam, weight repack) is replayed on its own stream under the discriminators' forward+backward.
+(G fwd+bwd | D fwd+bwd | Adam G + repack G | Adam D + repack D) and replayed.  Data parallel: a group's all-reduce is enqueued
+on the communication stream between the replays (default since round 3: one per optimiser group behind its phase graph).  In
+the staged form (stage_backward / UIG_DP_STAGED=1) each phase's backward pass is cut into stages (cyclegan._g_stages /
+_d_stages) and every stage is its own graph: bucket k's all-reduce is enqueued between the replays of stage k and stage k+1 and
+runs under the latter; with UIG_OVERLAP_UPDATE=1 the generator update graph (wait for the buckets, Adam, weight repack) is
+replayed on its own stream under the discriminators' forward+backward.
 Replaces a tracing compiler: one capture of the hand-written kernel sequence, no per-op host overhead afterwards."""
 from __future__ import annotations
 

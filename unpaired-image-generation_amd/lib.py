@@ -48,6 +48,9 @@ SIGNATURES = {
     "uig_conv_gather_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp] + [_i] * 15 + [_i, _f, _i, _vp]),
     "uig_conv_gather_bst": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp] + [_i] * 15 + [_i, _f, _i] + [_vp, _vp, _i, _f, _vp] + [_vp]),
     "uig_debug_set_in_tickets": (None, [_i]),
+    "uig_debug_set_in_fused": (None, [_i]),
+    "uig_instnorm_bwd_fused_applicable": (_i, [_i, _i64, _i, _i]),
+    "uig_instnorm_act_bwd_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _vp]),
     "uig_debug_set_colsum_slabs": (None, [_i]),
     "uig_conv_gather_fin": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp] + [_i] * 15 + [_i, _f, _i] + [_vp, _f, _vp] + [_vp]),
     "uig_reflect3x3_dgrad_mirror_bst": (_i, [_vp, _vp, _vp, _i, _vp, _vp] + [_i] * 7 + [_vp, _vp, _i, _f, _vp, _vp, _vp] + [_vp]),

@@ -43,8 +43,18 @@ IN_TICKETS = os.environ.get("UIG_IN_TICKETS", "0") != "0"
 # Round 4: the mirror-pixel input-gradient launch of a ResBlock convolution also emits the statistics of the InstanceNorm backward that
 # consumes its output (and finalises them): that norm's own statistics pass (a full read of dy and x) and its finalize launch are gone.
 MIRROR_BST = os.environ.get("UIG_MIRROR_BST", "0") != "0"
+# Round 4: the InstanceNorm backward as ONE launch and one pass over dy and x (statistics + finalize + apply fused, the blocks of an image
+# synchronise inside the kernel: include/uig.h, uig_instnorm_act_bwd_fused) wherever the whole grid can be resident at once (the ResBlock
+# maps of the 256x256 configurations, the PatchGAN's norms).  OPT-IN: measured slower on MI355X (scripts/bench_in_fused.py, 64x64x256
+# maps: 8 images 34.6 us vs 27.9 us for the three launches; 16 images 99 us vs 37 - the 1024-block grid equals the nominal residency
+# limit and does not become resident at once; whole step 15.29 vs 13.49 ms).  Each of the two in-kernel synchronisations costs ~8 us
+# (write-through drain, counter add, poll, sc1 re-read: four memory round trips of ~2 us), more than the two launch boundaries and the
+# second read of dy and x (from the 256-MB Infinity Cache) they replace.
+FUSED_IN_BWD = os.environ.get("UIG_FUSED_IN_BWD", "0") != "0"
 _TICKET_WORDS = 4096     # images per ticketed launch (one 32-bit word each) and family
-_TICKETS = {}            # device index -> zero int32 arena [2 * _TICKET_WORDS]: family 0 = forward statistics, 1 = backward statistics
+_TICKETS = {}            # device index -> int32 arena [3 * _TICKET_WORDS + 16], zero between launches: family 0 = forward statistics,
+                         # 1 = backward statistics, 2 = in-kernel synchronisation words of the fused backward (4 per image); the word at
+                         # 3 * _TICKET_WORDS is the fused kernels' error flag (a bounded in-kernel wait ran out): check_sync_errors
 
 
 def _dev_index(device) -> int:
@@ -62,7 +72,7 @@ def ticket_arena(device) -> torch.Tensor:
     if t is None:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("ops.ticket_arena(device) must be called once before the first graph capture")
-        t = _TICKETS[idx] = torch.zeros(2 * _TICKET_WORDS, device=torch.device("cuda", idx), dtype=torch.int32)
+        t = _TICKETS[idx] = torch.zeros(3 * _TICKET_WORDS + 16, device=torch.device("cuda", idx), dtype=torch.int32)
     return t
 
 
@@ -76,8 +86,24 @@ def _tickets(device, family: int, B: int):
 def reset_tickets(device) -> None:
     """zero the arena (one fill per train step, ahead of the first ticketed launch): a launch that was aborted mid-way cannot poison
     the following steps"""
-    if IN_TICKETS:
-        ticket_arena(device).zero_()
+    if IN_TICKETS or FUSED_IN_BWD:
+        ticket_arena(device)[:3 * _TICKET_WORDS].zero_()      # not the error flag
+
+
+def check_sync_errors(device) -> None:
+    """Raise if a fused kernel's bounded in-kernel wait ran out since the last check (its results were then garbage): that can only
+    happen when the kernel's grid was not fully resident - another stream's kernels holding compute units for longer than the ~1 s
+    bound, or fewer units than the occupancy query promised.  Reads one device word (a host synchronisation: call it where the host
+    synchronises anyway).  After an error the fused path is switched off for the rest of the process."""
+    global FUSED_IN_BWD
+    t = _TICKETS.get(_dev_index(device))
+    if t is None or not FUSED_IN_BWD:
+        return
+    if int(t[3 * _TICKET_WORDS].item()) != 0:
+        t[3 * _TICKET_WORDS:].zero_()
+        FUSED_IN_BWD = False
+        raise RuntimeError("uig: an in-kernel wait of the fused InstanceNorm backward timed out (grid not co-resident); its results were invalid. "
+                           "The fused path is now disabled for this process (UIG_FUSED_IN_BWD=0 selects the three-launch form from the start).")
 
 _SIDE_STREAMS = {}
 _DEFER_JOIN = {}
@@ -1025,6 +1051,24 @@ def instnorm_backward(dy, x, stats, act, slope, emit_mx=False):
     gm = getattr(dy, "_uig_bst_gm", None)
     if gm is not None and tuple(gm.shape) != (B, C, 2):
         gm = None
+    if FUSED_IN_BWD and gm is None and pre is None and not emit_mx and 4 * B <= _TICKET_WORDS:
+        nb = int(lib.uig_instnorm_bwd_fused_applicable(B, H * W, C, _dt(x)))
+        if nb > 0:      # one launch, one pass over dy and x: the blocks of an image synchronise inside the kernel
+            part = torch.empty((B * nb * C * 2,), device=x.device, dtype=torch.float32)
+            gmt = torch.empty((B * C * 2,), device=x.device, dtype=torch.float32)
+            cp = torch.empty((B * nb * C * 2,), device=x.device, dtype=torch.float32)
+            q = s = None
+            if emit_mx:
+                q = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+                s = torch.empty((B, H, W, C // 32), device=x.device, dtype=torch.uint8)
+            arena = ticket_arena(x.device).data_ptr()
+            L.check(lib.uig_instnorm_act_bwd_fused(_p(dy), _p(x), _p(stats), _p(dx), _p(part), _p(gmt), _p(cp), arena + 2 * _TICKET_WORDS * 4,
+                                                   arena + 3 * _TICKET_WORDS * 4, _p(q), _p(s), B, H * W, C, act, slope, _dt(x), _stream()),
+                    "uig_instnorm_act_bwd_fused")
+            if emit_mx:
+                dx._uig_mx = (q, s)
+            dx._uig_colsum = (cp, nb, C)
+            return dx
     if gm is not None or (IN_TICKETS and pre is None and B <= _TICKET_WORDS):
         # round 4: (mean g, mean g*xhat) final out of the launch that wrote dy -> the apply launch alone; else this norm's own statistics
         # pass finalises itself (two launches instead of three)
