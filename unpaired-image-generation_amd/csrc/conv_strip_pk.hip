@@ -259,6 +259,8 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
 
     unsigned long long tstamp[8];
     int nst = 0;
+    [[maybe_unused]] unsigned long long wsum = 0, bsum = 0;      // STAMP: per-wave sums over all K-steps: waitcnt, barrier
+    [[maybe_unused]] int nstep = 0;
     auto stamp = [&]() {
         if constexpr (STAMP) {
             if (nst < 8) {
@@ -398,9 +400,16 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
             for (int t = 0; t < NTAPS; ++t) {                   // fully unrolled: the row table is statically indexed
                 // this wave's DMAs (weight tile of this step, strip pieces) have landed and its fragment reads of the previous
                 // step are complete (the DMAs issued below overwrite that step's weight stage) ...
+                [[maybe_unused]] unsigned long long tw0 = 0, tw1 = 0, tw2 = 0;
+                if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tw0) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
                 if constexpr (LGK) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tw1) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
                 __builtin_amdgcn_s_barrier();                   // ... and everyone else's
+                if constexpr (STAMP) {                          // diagnostic: cycles this wave spent in the step's waitcnt / in its barrier
+                    __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tw2) :: "memory"); __builtin_amdgcn_sched_barrier(0);
+                    wsum += tw1 - tw0; bsum += tw2 - tw1; ++nstep;
+                }
                 const bool last_t = t + 1 == NTAPS;
                 const bool w_on = !(last_t && last_cc) || pre_next;
                 const bool w_g2 = (last_t && last_cc) ? nxt.g2 : cur.g2;
@@ -573,6 +582,8 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
         if (lane == 0 && d.dbg != nullptr) {
             unsigned long long* o = d.dbg + ((long)blockIdx.x * NW + wave) * 8;
             for (int i = 0; i < 8; ++i) o[i] = i < nst ? tstamp[i] : 0ull;
+            unsigned long long* o2 = d.dbg + (long)gridDim.x * NW * 8 + ((long)blockIdx.x * NW + wave) * 4;      // second table behind the stamps
+            o2[0] = wsum; o2[1] = bsum; o2[2] = (unsigned long long)nstep; o2[3] = 0ull;
         }
     }
 }
@@ -643,7 +654,7 @@ int uig_launch_strip_pk(const void* x, const void* wp, const float* bias, void* 
                 default: return launch_pk<bf16_t, 448, 5, 1, true, false, true, false, false, 4, false>(x, wp, bias, y, d, ntiles, s);  // four issuing waves
             }
         }
-        if (d.dbg != nullptr) return launch_pk<bf16_t, 448, 0, 1, true, true>(x, wp, bias, y, d, ntiles, s);
+        if (d.dbg != nullptr) return launch_pk<bf16_t, 448, 5, 1, true, true, false, false, false, 4, false>(x, wp, bias, y, d, ntiles, s);      // the default schedule, stamped
         switch (g_pk_dm) {      // tuning variants (A/B in one process: scripts/bench_strip_pk.py)
             case 20: return launch_pk<bf16_t, 448, 5, 1, true, false, false, false, false, 4, true>(x, wp, bias, y, d, ntiles, s);   // four issuing waves, packed row table
             case 21: return launch_pk<bf16_t, 448, 5, 1, true, false, false, false, false, 8, true>(x, wp, bias, y, d, ntiles, s);   // eight issuing waves, packed row table
