@@ -38,6 +38,8 @@ struct StripDesc {
     const float* nrm_stats;
     int nrm_act; float nrm_slope;
     void* nrm_h;
+    int abl;                 // diagnostic: timing ablations of the phased schedule (uig_debug_set_strip_pk, dm >> 8); 0 in every product launch
+    int need_rows;           // strip rows the worst 256-pixel tile needs (set by uig_try_conv_strip)
     int wide512;             // persistent bf16 kernel: 1 = the 512-row strip without zero rows (conv_strip_pk.hip, NOZ; set by uig_try_conv_strip)
     // round 4, persistent kernel: in-launch finalize (arrival tickets, uig_common.h) of the forward statistics (fin: in_partial -> (mean, rstd))
     // and of the norm-backward statistics (bfin: bst_partial -> (mean g, mean g*xhat)); tickets == NULL = off (the caller runs the finalize launch)

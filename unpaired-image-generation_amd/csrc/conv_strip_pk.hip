@@ -66,9 +66,12 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
     constexpr int BK = 8 * E;
     constexpr int BM = 256, BN = 128, NW = 8, NTAPS = 9, WM = 64, WN = 64, MT = 4, NT = 4;
     constexpr int PIECES = CAP / 8;
-    constexpr int SBUF = (CAP + (NOZ ? 0 : 8)) * 128, WSTG = BN * 128, REG = SBUF + WSTG;     // LDS: [strip 0][weights 0][strip 1][weights 1]
+    // PH (DM == 6, round 4): the phased schedule - three weight stages, LDS [strip 0][W0][W1][strip 1][W2] (see the K loop)
+    constexpr bool PH = DM == 6;
+    constexpr int SBUF = (CAP + (NOZ ? 0 : 8)) * 128, WSTG = BN * 128, REG = PH ? SBUF + 2 * WSTG : SBUF + WSTG;     // LDS: [strip 0][weights 0][strip 1][weights 1]
     constexpr int SCRW = 64 * 64 * (int)sizeof(T);                                  // one wave's epilogue scratch
-    constexpr bool XPREF = NW * SCRW <= REG;      // the scratch fits the region the last K-step used: prefetch the next tile behind the last chunk
+    constexpr bool XPREF = NW * SCRW <= SBUF + WSTG;      // the scratch fits the region the last K-step used: prefetch the next tile behind the last chunk
+    static_assert(!PH || (sizeof(T) == 2 && SWZ == 1 && XPREF && !NORM && !NOZ && NISS == 8 && 2 * SBUF + 3 * WSTG <= 163840), "phased schedule: bf16, eight issuing waves, 160 KB");
     constexpr int ZW = CAP * 128 / SCRW;          // the wave whose scratch covers the region's zero row
     static_assert(CAP % 8 == 0 && PIECES <= NTAPS * NW, "one strip piece per wave per K-step");
     static_assert(NOZ || !XPREF || (CAP * 128) % SCRW + 1024 <= SCRW, "zero row must lie inside one wave's scratch");
@@ -164,13 +167,32 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
         if (g2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw2, (__attribute__((address_space(3))) void*)dst, 16, (int)wvl0, soi, 0, 0);
         else    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw1, (__attribute__((address_space(3))) void*)dst, 16, (int)wvl0, soi, 0, 0);
     };
+    // PH: weight stage k of three (k = tap % 3: a tile has 36 = 0 mod 3 steps) and its two DMA pieces per wave; `on` false = a zero fill
+    // (out-of-range offset: no memory access) so that every step issues the same NUMBER of DMAs - the K loop's waits are counted
+    [[maybe_unused]] auto wst_off = [&](int k) -> int { return k == 2 ? REG + SBUF : SBUF + k * WSTG; };
+    [[maybe_unused]] auto issue_wph = [&](int i, bool g2, unsigned so, int stage, bool on) {
+        lds_ptr_t dst = (lds_ptr_t)smem + wst_off(stage) + (wave + NW * i) * 1024;
+        const int soi = (int)so + i * NW * 8 * d.ldw * (int)sizeof(T);
+        const unsigned vo = on ? wvl0 : 0xFFFFFFFFu;
+        if (g2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw2, (__attribute__((address_space(3))) void*)dst, 16, (int)vo, soi, 0, 0);
+        else    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw1, (__attribute__((address_space(3))) void*)dst, 16, (int)vo, soi, 0, 0);
+    };
     auto issue_first = [&](const Tile& t, int region) {       // a tile's chunk-0 strip and first weight tile, all at once
         const unsigned sb = strip_base(t, 0);
         for (int j = wave; 8 * j < t.NS; j += NW) issue_strip_piece(j, sb, t.NS, region);
+        if constexpr (PH) {                                    // taps 0 and 1 -> stages 0 and 1
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const unsigned so = w_base(t, k, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) issue_wph(i, t.g2, so, k, true);
+            }
+        } else {
         const unsigned so = w_base(t, 0, 0);
         if (wave < NISS) {
 #pragma unroll
             for (int i = 0; i < WPI; ++i) issue_w1(i, t.g2, so, region);
+        }
         }
     };
 
@@ -259,7 +281,8 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
 
     unsigned long long tstamp[8];
     int nst = 0;
-    [[maybe_unused]] unsigned long long wsum = 0, bsum = 0;      // STAMP: per-wave sums over all K-steps: waitcnt, barrier
+    [[maybe_unused]] unsigned long long r1sum = 0, r2sum = 0, r3sum = 0, r4sum = 0;      // phased STAMP: R = read issue | DMA issue | vmcnt wait | lgkmcnt wait
+    [[maybe_unused]] unsigned long long wsum = 0, bsum = 0, msum = 0, csum = 0;      // STAMP: per-wave sums over all K-steps: waitcnt, barrier (phased schedule: R, opening barrier, M, closing barrier)
     [[maybe_unused]] int nstep = 0;
     auto stamp = [&]() {
         if constexpr (STAMP) {
@@ -387,6 +410,114 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
 
         stamp();                                               // 1 / 4: K loop starts
         [[maybe_unused]] u32x4_t xn[MT];                       // DM == 5: the NEXT step's strip fragments of K half 0, read behind this step's MFMAs
+        if constexpr (PH) {
+        // ---- the phased schedule (round 4; after the guide's 256^2 eight-phase GEMM template).  A K-step (one tap, 64 channels) is
+        //   R: 16 fragment reads, the step's DMAs (strip piece, two weight pieces), the counted DMA wait, lgkmcnt(0) | barrier |
+        //   M: 32 MFMAs at raised priority | barrier.
+        // Waves 4-7 (the SIMD partners of waves 0-3) run ONE BARRIER BEHIND waves 0-3, so in every interval between two barriers one wave of
+        // each SIMD reads fragments and issues DMAs while the other owns the matrix pipe: the fragment round trip, the DMA issue and the
+        // barrier skew - what the one-barrier-per-step loop exposes in front of its MFMAs (~1650 cycles per step for 1024
+        // of MFMA) - sit behind the partner's MFMAs.  (First form: phases of one K HALF, 16 MFMAs between barriers like the template: the
+        // same launch time as the unphased loop - a barrier costs the pipe ~140 cycles whatever sits around it; hence whole steps.)
+        // Hazards (intervals I_k between barriers; group A = waves 0-3, B = waves 4-7; step s: A reads in I_2s, B in I_2s+1):
+        //   * weights of step s+2 go to stage (s+2) % 3 = the stage of step s-1, last read by B in I_2s-1 and RETIRED there (lgkmcnt(0) in
+        //     front of the barrier that ends the interval); issued by A in I_2s, by B in I_2s+1.
+        //   * a wave's DMAs of step s are waited for in step s+1's R phase, AFTER that step's own DMAs are issued, by vmcnt(3 | 2) = their
+        //     number (the same in every wave: zero fills stand in for pieces that do not exist): A in I_2s+2, B in I_2s+3; the barrier that
+        //     ends I_2s+3 publishes them; first read by A in I_2s+4.
+        //   * strip pieces of chunk c+1 (taps 0-6 of chunk c) go to the other strip region, last read in chunk c-1; landed and published
+        //     by the barrier behind tap 7's R phases; the mirror pixels are written in tap 8's R phase and retired there.
+        //   * end of tile: group B skips the closing barrier of the last step (nobody waits for those MFMAs) - the groups are level
+        //     again (equal barrier counts), the epilogues start without a wait; the scratch is [strip 1][W2]: the last chunk's strip and
+        //     the last tap's stage, neither a prefetch target (the next tile's chunk 0 and taps 0, 1 go to strip 0, W0, W1).  ncc is even
+        //     (host-checked), so a tile's last chunk is always in strip 1.
+        if (r == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the block's first strip chunk and weight tiles
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // ... and every wave's epilogue scratch reads / zero-row / mirror-pixel writes
+        __builtin_amdgcn_s_barrier();
+        if (wn == 1) __builtin_amdgcn_s_barrier();                          // group B: one barrier behind
+        const int abl = d.abl;                                              // timing ablations (diagnostic hook; 0 in every product launch)
+        u32x4_t xf[2][MT], wf[2][NT];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { xf[h][a] = u32x4_t{0u, 0u, 0u, 0u}; wf[h][a] = u32x4_t{0u, 0u, 0u, 0u}; }
+        for (int cc = 0; cc < ncc; ++cc) {
+            const int pc = par ^ (cc & 1);
+            const unsigned char* sx = smem + pc * REG;
+            const bool last_cc = cc + 1 == ncc;
+            const bool pre_next = last_cc && nxt.valid;
+            const bool s_on = !last_cc || pre_next;
+            const unsigned s_base = !last_cc ? strip_base(cur, cc + 1) : strip_base(nxt, 0);
+            const int s_NS = s_on ? (!last_cc ? cur.NS : nxt.NS) : 0;          // 0: zero fills
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) {
+                const bool wrap = t + 2 >= NTAPS;
+                const int t2 = wrap ? t + 2 - NTAPS : t + 2;
+                const bool w_on = !(wrap && last_cc) || pre_next;
+                const bool w_g2 = (wrap && last_cc) ? nxt.g2 : cur.g2;
+                const unsigned w_so = !wrap ? w_base(cur, t2, cc) : (!last_cc ? w_base(cur, t2, cc + 1) : w_base(nxt, t2, 0));
+                const unsigned char* sw = smem + wst_off(t % 3) + (wn * WN + l16) * 128;
+                [[maybe_unused]] unsigned long long tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0;      // STAMP: R | opening barrier | M | closing barrier
+                auto mt = [&](unsigned long long& v) {
+                    if constexpr (STAMP) { if (abl & 64) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } }
+                };
+                mt(tp0);
+                if constexpr (MIRROR) {
+                    if (t == NTAPS - 1 && s_on && !(d.mirror & 2)) mirror_fix(pc ^ 1, last_cc ? nxt : cur);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int co = ((q + 4 * h) ^ wswz) << 4;
+                    if (!(abl & 8)) {
+#pragma unroll
+                    for (int a = 0; a < NT; ++a) wf[h][a] = *reinterpret_cast<const u32x4_t*>(sw + a * 16 * 128 + co);
+                    }
+                    if (!(abl & 4)) {
+#pragma unroll
+                    for (int b = 0; b < MT; ++b) xf[h][b] = *reinterpret_cast<const u32x4_t*>(sx + (rt_get(t, b) ^ (unsigned)(h << 6)));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                [[maybe_unused]] unsigned long long tr1 = 0, tr2 = 0, tr3 = 0;      // STAMP: inside R (no wait behind these: the phase's lgkmcnt(0) retires them)
+                auto mtn = [&](unsigned long long& v) {
+                    if constexpr (STAMP) { if (abl & 128) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } }
+                };
+                mtn(tr1);
+                if (!(abl & 1)) {
+                if (t <= NTAPS - 3) issue_strip_piece(t * NW + wave, s_base, s_NS, pc ^ 1);
+                issue_wph(0, w_g2, w_so, t2 % 3, w_on);
+                issue_wph(1, w_g2, w_so, t2 % 3, w_on);
+                }
+                mtn(tr2);
+                if (abl & 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (t <= NTAPS - 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                mtn(tr3);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                mt(tp1);
+                if constexpr (STAMP) { r1sum += tr1 - tp0; r2sum += tr2 - tr1; r3sum += tr3 - tr2; r4sum += tp1 - tr3; }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                mt(tp2);
+                if (!(abl & 32)) __builtin_amdgcn_s_setprio(1);
+                if (!(abl & 16)) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int a = 0; a < NT; ++a)
+#pragma unroll
+                        for (int b = 0; b < MT; ++b) MmaS<T>::run(wf[h][a], xf[h][b], acc[a][b]);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                mt(tp3);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(wn == 1 && last_cc && t == NTAPS - 1)) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (STAMP) { mt(tp4); wsum += tp1 - tp0; bsum += tp2 - tp1; msum += tp3 - tp2; csum += tp4 - tp3; ++nstep; }
+            }
+        }
+        } else
         for (int cc = 0; cc < ncc; ++cc) {
             const int pc = par ^ (cc & 1);                     // region of this chunk's strip; weight stage of step t: pc ^ (t & 1)
             const unsigned char* sx = smem + pc * REG;
@@ -533,8 +664,10 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
         const int pl = par ^ ((ncc - 1) & 1);                  // region of the last chunk == weight stage of the last step (9 taps: odd)
 
         // ---- epilogue: scratch = the region the last K-step has just finished with (the prefetch went to the other one)
+        if constexpr (!PH) {                                    // (phased schedule: every read of region pl was retired in front of the last phase's first barrier)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                           // every wave is done reading region pl (raw: the prefetch DMAs stay in flight)
+        }
         unsigned char* scratch = smem + (XPREF ? pl * REG : 0) + wave * SCRW;
         // The epilogue's per-lane constants (LDS scratch addresses, row offsets, ...) all derive from the lane id.  Opaque to the
         // optimiser here, or it hoists them out of the tile loop and carries ~60 registers through the K loop (seen: 73 VGPRs
@@ -584,13 +717,16 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
             for (int i = 0; i < 8; ++i) o[i] = i < nst ? tstamp[i] : 0ull;
             unsigned long long* o2 = d.dbg + (long)gridDim.x * NW * 8 + ((long)blockIdx.x * NW + wave) * 4;      // second table behind the stamps
             o2[0] = wsum; o2[1] = bsum; o2[2] = (unsigned long long)nstep; o2[3] = 0ull;
+            if constexpr (PH) { unsigned long long* o3 = d.dbg + (long)gridDim.x * NW * 12 + ((long)blockIdx.x * NW + wave) * 2; o3[0] = msum; o3[1] = csum;
+                unsigned long long* o4 = d.dbg + (long)gridDim.x * NW * 14 + ((long)blockIdx.x * NW + wave) * 4; o4[0] = r1sum; o4[1] = r2sum; o4[2] = r3sum; o4[3] = r4sum; }
         }
     }
 }
 
 static int g_pk_dm = 0;        // tuning hook: variant of the bf16 kernel (see the switch in uig_launch_strip_pk)
 static int g_pk_grid = 0;      // tuning hook: persistent grid size (0 = one block per CU)
-extern "C" void uig_debug_set_strip_pk(int dm, int grid) { g_pk_dm = dm; g_pk_grid = grid; }
+static int g_pk_abl = 0;       // diagnostic: timing ablations of the phased schedule (bits: 1 no DMAs, 2 uncounted wait, 4 / 8 no strip / weight fragment reads, 16 no MFMAs, 32 no priority)
+extern "C" void uig_debug_set_strip_pk(int dm, int grid) { g_pk_abl = dm >> 8; g_pk_dm = dm & 255; g_pk_grid = grid; }
 
 static int device_cus() {
     static const int n = [] {
@@ -603,7 +739,7 @@ static int device_cus() {
 
 template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false, bool MIRROR = false, bool NORM = false, bool NOZ = false, int NISS = 8, bool PKRT = false, bool BST = false>
 static int launch_pk(const void* x, const void* wp, const float* bias, void* y, const StripDesc& d, int ntiles, hipStream_t s) {
-    const size_t smem = 2 * ((size_t)(CAP + (NOZ ? 0 : 8)) * 128 + 128 * 128) + (NORM ? (size_t)4 * 256 * 8 : 0);      // NORM: (mean, rstd) of 4 images x <= 256 channels
+    const size_t smem = 2 * ((size_t)(CAP + (NOZ ? 0 : 8)) * 128 + 128 * 128) + (NORM ? (size_t)4 * 256 * 8 : 0) + (DM == 6 ? 128 * 128 : 0);      // NORM: (mean, rstd) of 4 images x <= 256 channels; DM 6: a third weight stage
     auto kern = conv_strip_pk_kernel<T, CAP, DM, SWZ, LGK, STAMP, MIRROR, NORM, NOZ, NISS, PKRT, BST>;
     static SmemAttrOnce attr_once;
     {
@@ -639,6 +775,14 @@ int uig_launch_strip_pk(const void* x, const void* wp, const float* bias, void* 
         return launch_pk<bf16_t, 448, 5, 1, true, false, false, true>(x, wp, bias, y, d, ntiles, s);
     }
     if (dtype == UIG_BF16) {
+        // round 4: the phased schedule (DM 6): an even number of 64-channel chunks, at most 440 strip rows (the third weight stage's LDS)
+        d.abl = g_pk_abl;
+        const bool ph_ok = (d.Cin / 64) % 2 == 0 && d.need_rows <= 440 && d.bst_partial == nullptr;
+        if (g_pk_dm == 6 && ph_ok && d.dbg != nullptr && !d.mirror) return launch_pk<bf16_t, 440, 6, 1, true, true, false, false, false, 8, true>(x, wp, bias, y, d, ntiles, s);   // stamped
+        if (g_pk_dm == 6 && ph_ok && d.dbg == nullptr) {
+            if (d.mirror) return launch_pk<bf16_t, 440, 6, 1, true, false, true, false, false, 8, true>(x, wp, bias, y, d, ntiles, s);      // packed row table: no scratch
+            return launch_pk<bf16_t, 440, 6, 1, true, false, false, false, false, 8, false>(x, wp, bias, y, d, ntiles, s);
+        }
         if (d.mirror) {
             if (d.dbg != nullptr) return launch_pk<bf16_t, 448, 0, 1, true, true, true>(x, wp, bias, y, d, ntiles, s);
             // round 4: the variant whose epilogue also emits the statistics of the InstanceNorm backward that consumes dx
