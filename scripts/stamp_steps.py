@@ -10,7 +10,7 @@ lib = u.lib.lib()
 dt = torch.bfloat16
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 PHASED = "phased" in sys.argv[2:]
-if PHASED: lib.uig_debug_set_strip_pk(6 | 64 << 8, 0)      # bit 64 of the ablation word: per-step stamps on
+if PHASED: lib.uig_debug_set_strip_pk(6 | (192 if 'split' in sys.argv else 64) << 8, 0)      # bit 64 of the ablation word: per-step stamps on
 l1 = networks.ConvLayer("conv", 256, 256, 3, 1, 1, "reflect", dtype=dt, device="cuda"); l1.repack()
 l2 = networks.ConvLayer("conv", 256, 256, 3, 1, 1, "reflect", dtype=dt, device="cuda"); l2.repack()
 x = (torch.rand(B, 64, 64, 256, device="cuda") * 2 - 1).to(dt)
