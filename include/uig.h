@@ -51,7 +51,8 @@ void uig_debug_set_strip_wide(int on);   /* 1 (default): reflection-padded 3x3 f
 /* tuning hook of the persistent strip kernel: dm = K-loop variant (0 default: DMA issue at the top of the K-step, the next step's
  * strip fragments read behind this step's MFMAs; 12 = without that prefetch; 2 / 4 / 8 / 9 / 10 = the rejected variants of DESIGN
  * §3.2), grid = persistent grid size (0 = one block per CU) */
-void uig_debug_set_strip_pk(int dm, int grid);
+void uig_debug_set_strip_pk(int dm, int grid);      /* dm: 0 default (round 4: the phased schedule where it applies), 5 round 3's schedule, 12/20/21/23 older A/B variants */
+long uig_debug_strip_pk_phased_count(void);          /* launches so far that ran the phased schedule (tests) */
 /* tuning / test hook: 1 (default) = uig_reflect3x3_dgrad_mirror_applicable may say 1; 0 = it never does (A/B against the border GEMM);
  * 3 / 5 / 7 = diagnostic timing builds of the mirror kernel WITHOUT its per-chunk / first-chunk / any mirror sums (wrong results:
  * scripts/bench_dgrad_mirror.py and scripts/stamp_strip_pk.py only) */

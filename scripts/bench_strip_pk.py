@@ -19,7 +19,7 @@ def t(fn, n=40):
     e1.record(); e1.synchronize(); return e0.elapsed_time(e1) * 1e3 / n
 VARIANTS = {"tile/block": (3, 0, 0), "pk": (1, 0, 0), "pk no-xprefetch": (1, 12, 0), "pk nolgk": (1, 4, 0), "pk rd0-dma": (1, 8, 0), "pk rdall-dma": (1, 9, 0), "pk setprio": (1, 10, 0),
             "pk 4iss": (1, 20, 0), "pk pkrt": (1, 21, 0), "pk 8iss": (1, 23, 0),
-            "pk phased": (1, 6, 0), "pk inter": (1, 7, 0), "pk phasedM": (1, 8, 0)}      # round 4: two wave groups one barrier apart, three weight stages, counted DMA waits      # round 3: "pk" issues its DMAs from four waves; 20 / 21: packed row table with four / eight issuing waves; 23: round 2's eight
+            "pk r3": (1, 5, 0)}      # round 4: "pk" = the phased schedule (two wave groups one barrier apart, three weight stages, counted DMA waits); "pk r3": round 3's default      # round 3: "pk" issues its DMAs from four waves; 20 / 21: packed row table with four / eight issuing waves; 23: round 2's eight
 if os.environ.get("PK_VARIANTS"):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k == "tile/block" or k in os.environ["PK_VARIANTS"].split(",")}
 lib.uig_debug_set_mirror(0)      # the input gradient in its border-buffer form on every variant, so that dx is comparable bitwise
@@ -56,7 +56,7 @@ lib.uig_debug_set_strip(1); lib.uig_debug_set_strip_pk(0, 0); lib.uig_debug_set_
 lib.uig_debug_set_mirror(1)
 mres, mref = {}, {}
 for rnd in range(3):
-    for v in [k for k in ("pk", "pk 4iss", "pk pkrt", "pk 8iss", "pk phased", "pk phasedM") if k in VARIANTS]:
+    for v in [k for k in ("pk", "pk r3", "pk 4iss", "pk pkrt", "pk 8iss") if k in VARIANTS]:
         select(v)
         for B in (16, 8):
             x = (torch.rand(B, 64, 64, 256, device="cuda", generator=torch.Generator("cuda").manual_seed(B)) * 2 - 1).to(dt)

@@ -1270,3 +1270,52 @@ def test_strip64_small_grid_variant_equals_128_tile_kernel(S, cin, cout, B, grou
                      for (a, e), l in zip(((0, g), (g, B)), ls) if e > a])
     got = ops.from_nhwc(outs[1][0], cout).float().cpu()
     assert (got - ref).abs().max() <= 1.6e-2 * ref.abs().max()
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,group,pm", [
+    (16, 64, 64, 256, 256, 8, "reflect"),     # the bench launch: 512 tiles, two per block, the weight set changes between a block's tiles
+    (8, 64, 64, 256, 256, 0, "reflect"),      # one tile per block
+    (24, 64, 64, 256, 256, 12, "reflect"),    # three tiles per block
+    (9, 64, 64, 256, 256, 4, "reflect"),      # 288 tiles: 32 blocks walk two tiles, the rest one; uneven pair
+    (6, 64, 64, 256, 256, 0, "zero"),        # 192 tiles on 256 CUs: a grid smaller than the chip; zero padding (zero-row reads)
+    (16, 64, 64, 128, 128, 0, "reflect"),     # two 64-channel chunks, one channel tile
+    (16, 64, 32, 256, 256, 8, "zero"),       # 32-pixel-wide map: 10-line strips (320 rows)
+    (12, 32, 64, 128, 256, 0, "reflect"),     # 32 x 64 map, chunk count 2, two channel tiles
+], ids=["bench16", "single8", "three-tiles", "uneven9", "grid192-zero", "c128", "w32-zero", "h32-c128"])
+def test_strip_persistent_phased_schedule_equals_round3_schedule_bitwise(B, H, W, cin, cout, group, pm):
+    """Round 4: the persistent strip kernel's K loop runs the PHASED schedule by default (conv_strip_pk.hip, DM 9: two wave groups one
+    barrier apart, three weight stages, counted LDS-DMA waits, the third stage in what used to be spare LDS) - a new synchronisation
+    structure.  Same arithmetic in the same order as round 3's loop, so every output must be BITWISE equal to it: forward + fused
+    InstanceNorm partial statistics, the mirror-pixel input gradient with the skip gradient (64-wide maps) or the plain transposed
+    gather.  Race screen: 12 launches per shape on fresh random data, over shapes that vary tiles per block (1, 2, 3, mixed), grid
+    size, chunk count, map width, padding and pairing.  (The oracle parity of both schedules: test_strip_persistent_256x128_bench_shape
+    and the step tests.)"""
+    u, ops, networks = _mods()
+    lib, dt = u.lib.lib(), torch.bfloat16
+    assert lib.uig_conv_strip_tile(B, H, W, cin, cout, H, W, -1, 1, u.lib.BF16) == 257
+    torch.manual_seed(4000 + B + W)
+    ls = [networks.ConvLayer("conv", cin, cout, 3, 1, 1, pm, dtype=dt, device="cuda") for _ in range(2)]
+    for l in ls: l.repack()
+    pair_f = (ls[1].wp_fwd, ls[1].bias, group) if group else None
+    pair_g = (ls[1].wp_dgrad, None, group) if group else None
+    gen = torch.Generator("cuda").manual_seed(17)
+    try:
+        for rep in range(12):
+            x = (torch.rand(B, H, W, cin, device="cuda", generator=gen) * 2 - 1).to(dt)
+            dy = (torch.randn(B, H, W, cout, device="cuda", generator=gen) * 0.5).to(dt)
+            res = (torch.randn(B, H, W, cin, device="cuda", generator=gen) * 0.5).to(dt)
+            out = {}
+            for dm in (5, 0):
+                lib.uig_debug_set_strip_pk(dm, 0)
+                n0 = lib.uig_debug_strip_pk_phased_count()
+                y = ops.conv_forward(ls[0].spec, x, ls[0].wp_fwd, ls[0].bias, pair=pair_f, want_in_stats=True)
+                assert lib.uig_debug_last_conv_kernel() == u.lib.K_STRIP_PK
+                dx = ops.conv_dgrad(ls[0].spec, dy, ls[0].wp_dgrad, (H, W), pair=pair_g, res_add=res)
+                nph = lib.uig_debug_strip_pk_phased_count() - n0      # (h32-c128: the input gradient has 96 tiles - not a persistent-kernel launch)
+                assert nph == (0 if dm == 5 else (1 if (H, cin) == (32, 128) else 2)), "the launches must take the schedule under test"
+                out[dm] = (y, y._uig_in_partial[0].clone(), dx)
+            torch.cuda.synchronize()
+            for name, a, b in zip(("y", "statistics", "dx"), out[5], out[0]):
+                assert torch.equal(a, b), f"repetition {rep}: {name} of the phased schedule differs from round 3's ({int((a != b).sum())} elements)"
+    finally:
+        lib.uig_debug_set_strip_pk(0, 0)

@@ -38,7 +38,7 @@ struct StripDesc {
     const float* nrm_stats;
     int nrm_act; float nrm_slope;
     void* nrm_h;
-    int abl;                 // diagnostic: timing ablations of the phased schedule (uig_debug_set_strip_pk, dm >> 8); 0 in every product launch
+    int wt_a, wt_b;          // persistent kernel, lean phased schedule: weight-tap index of tap t = wt_a + wt_b * t (set by uig_launch_strip_pk)
     int need_rows;           // strip rows the worst 256-pixel tile needs (set by uig_try_conv_strip)
     int wide512;             // persistent bf16 kernel: 1 = the 512-row strip without zero rows (conv_strip_pk.hip, NOZ; set by uig_try_conv_strip)
     // round 4, persistent kernel: in-launch finalize (arrival tickets, uig_common.h) of the forward statistics (fin: in_partial -> (mean, rstd))

@@ -19,6 +19,7 @@
 //     top of the step while the matrix pipe idles.
 #include "conv_strip_desc.h"
 #include <algorithm>
+#include <type_traits>
 
 // SWZ: strip swizzle (1 = rotation, 0 = the XOR of conv_igemm.hip); LGK: wait for this wave's own fragment reads before the
 // K-step barrier (strictly orders them before the DMA that overwrites the weight stage; 0 = rely on the DMA's latency as the
@@ -66,9 +67,8 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
     constexpr int BK = 8 * E;
     constexpr int BM = 256, BN = 128, NW = 8, NTAPS = 9, WM = 64, WN = 64, MT = 4, NT = 4;
     constexpr int PIECES = CAP / 8;
-    // PH (DM == 6, round 4): the phased schedule - three weight stages, LDS [strip 0][W0][W1][strip 1][W2] (see the K loop)
-    constexpr bool PH = DM == 6 || DM == 7 || DM == 8;      // three weight stages
-    constexpr bool IL = DM == 7;                  // ... and the interleaved schedule (see the K loop)
+    // PH (DM == 9, round 4): the phased schedule - three weight stages, LDS [strip 0][W0][W1][strip 1][W2] (see the K loop)
+    constexpr bool PH = DM == 9;
     constexpr int SBUF = (CAP + (NOZ ? 0 : 8)) * 128, WSTG = BN * 128, REG = PH ? SBUF + 2 * WSTG : SBUF + WSTG;     // LDS: [strip 0][weights 0][strip 1][weights 1]
     constexpr int SCRW = 64 * 64 * (int)sizeof(T);                                  // one wave's epilogue scratch
     constexpr bool XPREF = NW * SCRW <= SBUF + WSTG;      // the scratch fits the region the last K-step used: prefetch the next tile behind the last chunk
@@ -181,9 +181,9 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
     auto issue_first = [&](const Tile& t, int region) {       // a tile's chunk-0 strip and first weight tile, all at once
         const unsigned sb = strip_base(t, 0);
         for (int j = wave; 8 * j < t.NS; j += NW) issue_strip_piece(j, sb, t.NS, region);
-        if constexpr (PH) {                                    // taps 0 and 1 -> stages 0 and 1 (interleaved schedule: and tap 2 -> stage 2)
+        if constexpr (PH) {                                    // taps 0 and 1 -> stages 0 and 1 
 #pragma unroll
-            for (int k = 0; k < (IL ? 3 : 2); ++k) {
+            for (int k = 0; k < 2; ++k) {
                 const unsigned so = w_base(t, k, 0);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) issue_wph(i, t.g2, so, k, true);
@@ -282,8 +282,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
 
     unsigned long long tstamp[8];
     int nst = 0;
-    [[maybe_unused]] unsigned long long r1sum = 0, r2sum = 0, r3sum = 0, r4sum = 0;      // phased STAMP: R = read issue | DMA issue | vmcnt wait | lgkmcnt wait
-    [[maybe_unused]] unsigned long long wsum = 0, bsum = 0, msum = 0, csum = 0;      // STAMP: per-wave sums over all K-steps: waitcnt, barrier (phased schedule: R, opening barrier, M, closing barrier)
+    [[maybe_unused]] unsigned long long wsum = 0, bsum = 0;      // STAMP: per-wave sums over all K-steps: waitcnt, barrier
     [[maybe_unused]] int nstep = 0;
     auto stamp = [&]() {
         if constexpr (STAMP) {
@@ -386,11 +385,6 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
         }
     };
 
-    [[maybe_unused]] unsigned long long tpk = 0;               // DM 8: the nine weight-tap indices, four bits each
-    if constexpr (DM == 8) {
-#pragma unroll
-        for (int t = 0; t < NTAPS; ++t) tpk |= (unsigned long long)((d.tap[t] >> 16) & 15) << (4 * t);
-    }
     const int wswz = (l16 >> 1) & 7;
     int par = 0;                                               // region holding chunk 0 of the current tile
     for (int r = 0;; ++r) {
@@ -416,148 +410,68 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
 
         stamp();                                               // 1 / 4: K loop starts
         [[maybe_unused]] u32x4_t xn[MT];                       // DM == 5: the NEXT step's strip fragments of K half 0, read behind this step's MFMAs
-        if constexpr (IL) {
-        // ---- the interleaved schedule (round 4).  What the phased schedule below taught (its ablations, scripts/ablate_phased.py): the
-        // fragment reads and DMA issue of one wave do NOT hide behind the MFMAs of its SIMD partner - the launch time is close to the sum of
-        // the two, whichever way the waves are arranged around the barriers.  What does hide (MI355X_MICROARCH.md, LDS: reads issued between
-        // the MFMAs of the SAME wave cost ~3 cycles per gap) is a wave's own next fragments under its own MFMAs.  A K-step (one tap, 64
-        // channels) of every wave:
-        //   A: 16 MFMAs of K half 0 (fragment set 0, in registers since the previous step) with the 8 reads of half 1 -> set 1 between them
-        //      vmcnt(N): this wave's DMAs of step t-2 and older have landed | lgkmcnt(0) | barrier
-        //   B: 16 MFMAs of half 1 (set 1) with the 8 reads of step t+1's half 0 -> set 0 and this step's DMAs between them:
-        //      weights of step t+3 -> stage t % 3 (its last reads - this step's half 1 - were retired in front of the barrier),
-        //      strip piece t * 8 + wave of the next chunk (taps 0-6).
-        // One barrier per step, in the MIDDLE of it: behind it the half-1 fragments are already in registers, in front of it the matrix
-        // pipe still holds the last MFMAs of half 0.  A DMA issued in B(t) is waited for in A(t+2) by vmcnt(number of DMAs of B(t+1)): two
-        // steps to land; first read in B(t+2) (weights of step t+3, half 0) behind barrier(t+2).
-        // Tile boundary: B of the last step reads nothing and issues nothing (stage 2 = the last tap's stage joins the last chunk's strip
-        // as the epilogue scratch; the next tile's taps 0 and 1 went to stages 0 and 1 in the two steps before); the next tile starts with
-        // vmcnt(0) | barrier, the DMA of its tap 2 and its first half-0 fragments read in the open (once per tile).
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (r > 0) {                                                        // (the block's first tile: issue_first loaded all three stages)
-            const unsigned so2 = w_base(cur, 2, 0);
-            issue_wph(0, cur.g2, so2, 2, true);
-            issue_wph(1, cur.g2, so2, 2, true);
-        }
-        u32x4_t xf0[MT], wf0[NT], xf1[MT], wf1[NT];
-        {
-            const unsigned char* sx0 = smem + par * REG;
-            const unsigned char* sw0 = smem + wst_off(0) + (wn * WN + l16) * 128;
-            const int co = (q ^ wswz) << 4;
-#pragma unroll
-            for (int a = 0; a < NT; ++a) wf0[a] = *reinterpret_cast<const u32x4_t*>(sw0 + a * 16 * 128 + co);
-#pragma unroll
-            for (int b = 0; b < MT; ++b) xf0[b] = *reinterpret_cast<const u32x4_t*>(sx0 + rt_get(0, b));
-        }
-        for (int cc = 0; cc < ncc; ++cc) {
-            const int pc = par ^ (cc & 1);
-            const unsigned char* sx = smem + pc * REG;
-            const bool last_cc = cc + 1 == ncc;
-            const bool pre_next = last_cc && nxt.valid;
-            const bool s_on = !last_cc || pre_next;
-            const unsigned s_base = !last_cc ? strip_base(cur, cc + 1) : strip_base(nxt, 0);
-            const int s_NS = s_on ? (!last_cc ? cur.NS : nxt.NS) : 0;          // 0: zero fills
-#pragma unroll
-            for (int t = 0; t < NTAPS; ++t) {
-                const bool wrap = t + 3 >= NTAPS;
-                const int t3 = wrap ? t + 3 - NTAPS : t + 3;
-                const bool w_on = !(wrap && last_cc) || pre_next;
-                const bool w_g2 = (wrap && last_cc) ? nxt.g2 : cur.g2;
-                const unsigned w_so = !wrap ? w_base(cur, t3, cc) : (!last_cc ? w_base(cur, t3, cc + 1) : w_base(nxt, t3, 0));
-                const unsigned char* sw = smem + wst_off(t % 3) + (wn * WN + l16) * 128;
-                // ---- A: half 0 from set 0; half 1 -> set 1
-                __builtin_amdgcn_sched_barrier(0);
-                {
-                    const int co = ((q + 4) ^ wswz) << 4;
-#pragma unroll
-                    for (int a = 0; a < NT; ++a) wf1[a] = *reinterpret_cast<const u32x4_t*>(sw + a * 16 * 128 + co);
-#pragma unroll
-                    for (int b = 0; b < MT; ++b) xf1[b] = *reinterpret_cast<const u32x4_t*>(sx + (rt_get(t, b) ^ 64u));
-#pragma unroll
-                    for (int a = 0; a < NT; ++a)
-#pragma unroll
-                        for (int b = 0; b < MT; ++b) MmaS<T>::run(wf0[a], xf0[b], acc[a][b]);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (t >= 1 && t <= NTAPS - 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");      // = the DMAs of B(t-1): taps 0-6 issue a strip piece
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- B: half 1 from set 1; next step's half 0 -> set 0; this step's DMAs
-                {
-                    const bool tile_end = last_cc && t == NTAPS - 1;
-                    if (!tile_end) {
-                        const int tn = (t + 1) % NTAPS;
-                        const unsigned char* sxn = t + 1 < NTAPS ? sx : smem + (pc ^ 1) * REG;
-                        const unsigned char* swn = smem + wst_off(tn % 3) + (wn * WN + l16) * 128;
-                        const int co = (q ^ wswz) << 4;
-#pragma unroll
-                        for (int a = 0; a < NT; ++a) wf0[a] = *reinterpret_cast<const u32x4_t*>(swn + a * 16 * 128 + co);
-#pragma unroll
-                        for (int b = 0; b < MT; ++b) xf0[b] = *reinterpret_cast<const u32x4_t*>(sxn + rt_get(tn, b));
-                        if (t <= NTAPS - 3) issue_strip_piece(t * NW + wave, s_base, s_NS, pc ^ 1);
-                        issue_wph(0, w_g2, w_so, t % 3, w_on);
-                        issue_wph(1, w_g2, w_so, t % 3, w_on);
-                    }
-#pragma unroll
-                    for (int a = 0; a < NT; ++a)
-#pragma unroll
-                        for (int b = 0; b < MT; ++b) MmaS<T>::run(wf1[a], xf1[b], acc[a][b]);
-                    if (!tile_end) {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                            if (i == 1 || i == 3 || i == 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                        }
-                    }
-                }
-            }
-        }
-        } else if constexpr (DM == 8) {
-        // ---- the phased schedule, DMA issue inside the M phase (round 4).  The phased schedule below (DM 6) keeps the step's DMA issue - three
-        // instructions and ~17 of scalar / vector address arithmetic - in the R phase, which that makes the longer of the two: ~700 cycles
-        // against the M phase's 530 (in-kernel stamps).  scripts/probes/mfma_coissue.hip: the same instructions placed between a wave's OWN
-        // MFMAs cost the M phase ~60 cycles (and 16 fragment reads of the SIMD partner run beside it in 256 = the LDS array's rate for
-        // 64 KB).  So:   R: 16 fragment reads | lgkmcnt(0) | barrier |   M: 32 MFMAs with the step's DMAs between them | vmcnt(N) | barrier.
-        // Group A (waves 0-3) issues in M(u) its pieces of step u+2's weight tile, group B (waves 4-7, one barrier behind) its pieces of
-        // step u+3's; both wait at the END of M(u) for what they issued in M(u-1) (vmcnt(N), N = the DMAs of M(u) itself):
-        //   intervals I_k between barriers; step s: A reads in I_2s, B in I_2s+1; A's M(u) = I_2u+1, B's M(u) = I_2u+2
-        //   * stage of step s (s % 3) is free once B's reads of step s are retired: end of I_2s+1.  A writes it for step s+3 in M(s+1) =
-        //     I_2s+3, B in M(s) = I_2s+2.
-        //   * weights of step s must be published by the barrier that ends I_2s-1: A issued them in M(s-2) and waits at the end of M(s-1)
-        //     = I_2s-1; B issued in M(s-3), waits at the end of M(s-2) = I_2s-2.  Two intervals of flight for every DMA.
-        //   * strip pieces of the next chunk: taps 0-6, same rule: the last (tap 6) are waited for in I_15 (A) / I_16 (B) of the chunk,
-        //     the next chunk's first read is A's in I_18.  Mirror pixels: written in I_17 (A: at the head of M(8), B: at the head of R(8)).
-        //   * tile end: B issues nothing in M(35) (step 38 = the next tile's tap 2 would go to stage 2 = part of the epilogue scratch):
-        //     it issues those two pieces at the head of the next tile instead.
+        if constexpr (DM == 9) {
+        // ---- the phased schedule (round 4; after the guide's 256^2 eight-phase GEMM template).  A K-step (one tap, 64 channels) of a wave is
+        //   R: 16 fragment reads, the step's three DMAs (strip piece, two weight pieces), the counted DMA wait, lgkmcnt(0) | barrier |
+        //   M: 32 MFMAs | barrier.
+        // Waves 4-7 (group B, the SIMD partners of waves 0-3 = group A) run ONE BARRIER BEHIND group A, so in every interval between two
+        // barriers one wave of each SIMD reads fragments and issues DMAs while the other owns the matrix pipe.  What the probes say about this
+        // skeleton on gfx950 (scripts/probes/mfma_coissue.hip): with R = 16 ds_read_b128 (+ 16 VALU adds, + 3 LDS-DMA pieces) a step takes
+        // 1025 cycles for its 1024 of MFMA - barriers, the partner's reads and DMA issue cost the matrix pipe nothing - but 20 SCALAR
+        // instructions in R make it 1385, the DMAs between the MFMAs of the M phase 1185, all eight waves in step (R | barrier | M) 1357.
+        // Hence the LEAN R phase: running offsets advanced by one instruction each (explicit asm: left to itself the optimiser turns a
+        // running offset of an unrolled loop back into nine recomputations from the tap table), the wave's second weight piece through its
+        // own lane-offset register instead of a second scalar offset, the strip piece's validity by a per-lane running row index (VALU),
+        // the last chunk of a tile as its own instance of the step body so that everything depending on "last chunk" is decided at compile
+        // time.  Measured (in-kernel stamps, scripts/stamp_lean.py): 1182-1190 cycles per K-step against ~1650 for round 3's loop; the
+        // launch is faster by 6-7 % only - the chip runs this kernel AT ITS POWER LIMIT (rocm-smi: 1350-1360 W of 1400 under either schedule)
+        // and lowers the clock as the matrix pipe fills (2.24 -> 2.07 GHz): DESIGN.md 5.000.
+        // (Tried on the way, all bitwise equal: phases of one K half - 16 MFMAs between barriers like the template - the same time as
+        // whole steps; the next half's fragments read between the wave's own MFMAs, one barrier per step: no gain; the DMA issue moved
+        // into the M phase: slower.)
+        // Hazards (intervals I_k between barriers; step s: A reads in I_2s, B in I_2s+1):
+        //   * weights of step s+2 go to stage (s+2) % 3 = the stage of step s-1 (a tile has 36 = 0 mod 3 steps: the stage of a tap is
+        //     tap % 3), last read by B in I_2s-1 and RETIRED there (lgkmcnt(0) in front of the barrier that ends the interval); issued by
+        //     A in I_2s, by B in I_2s+1.
+        //   * a wave's DMAs of step s are waited for in step s+1's R phase, AFTER that step's own DMAs are issued, by vmcnt(3 | 2) = their
+        //     number (the same in every wave: zero fills stand in for pieces that do not exist): A in I_2s+2, B in I_2s+3; the barrier that
+        //     ends I_2s+3 publishes them; first read by A in I_2s+4.
+        //   * strip pieces of chunk c+1 (taps 0-6 of chunk c; piece 55 = a zero fill of the strip's zero rows) go to the other strip
+        //     region, last read in chunk c-1; landed and published by the barrier behind tap 7's R phases; the mirror pixels are written
+        //     in tap 8's R phase and retired there.
+        //   * end of tile: group B skips the closing barrier of the last step (nobody waits for those MFMAs) - the groups are level
+        //     again (equal barrier counts), the epilogues start without a wait; the scratch is [strip 1][W2]: the last chunk's strip and
+        //     the last tap's stage, neither a prefetch target (the next tile's chunk 0 and taps 0, 1 go to strip 0, W0, W1).  The number
+        //     of chunks is even (host-checked), so a tile's last chunk is always in strip 1.
         if (r == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the block's first strip chunk and weight tiles
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // ... and every wave's epilogue scratch reads / zero-row / mirror-pixel writes
         __builtin_amdgcn_s_barrier();
-        if (wn == 1) {
-            const unsigned so2 = w_base(cur, 2, 0);                         // group B's pieces of tap 2 (group A issues its own in M(0))
-            issue_wph(0, cur.g2, so2, 2, true);
-            issue_wph(1, cur.g2, so2, 2, true);
-            __builtin_amdgcn_s_barrier();                                   // group B: one barrier behind
-        }
-        for (int cc = 0; cc < ncc; ++cc) {
+        if (wn == 1) __builtin_amdgcn_s_barrier();                          // group B: one barrier behind
+        const int inc_tap = __builtin_amdgcn_readfirstlane(d.wt_b * Cin * (int)sizeof(T));
+        const int inc_wrap = __builtin_amdgcn_readfirstlane(BK * (int)sizeof(T) - 8 * inc_tap);            // tap 8 of chunk c -> tap 0 of chunk c + 1
+        const int k64 = __builtin_amdgcn_readfirstlane(64 * Cin * (int)sizeof(T));                          // 8 strip pieces further
+        int w_run = __builtin_amdgcn_readfirstlane((cur.n_base * d.ldw + (d.wt_a + 2 * d.wt_b) * Cin) * (int)sizeof(T));      // tap 2, chunk 0
+        const int w_next0 = __builtin_amdgcn_readfirstlane((nxt.n_base * d.ldw + d.wt_a * Cin) * (int)sizeof(T));             // the next tile's tap 0, chunk 0
+        const __amdgpu_buffer_rsrc_t rs_cur = cur.g2 ? rsw2 : rsw1, rs_nxt = nxt.g2 ? rsw2 : rsw1;
+        const unsigned wvl1 = wvl0 + (unsigned)(NW * 8 * d.ldw * (int)sizeof(T));                           // the wave's second piece: 64 rows further
+        auto chunk = [&](auto lastc, int cc) {
+            constexpr bool LASTC = decltype(lastc)::value;
             const int pc = par ^ (cc & 1);
             const unsigned char* sx = smem + pc * REG;
-            const bool last_cc = cc + 1 == ncc;
-            const bool pre_next = last_cc && nxt.valid;
-            const bool s_on = !last_cc || pre_next;
-            const unsigned s_base = !last_cc ? strip_base(cur, cc + 1) : strip_base(nxt, 0);
-            const int s_NS = s_on ? (!last_cc ? cur.NS : nxt.NS) : 0;          // 0: zero fills
+            const bool pre_next = LASTC && nxt.valid;
+            const bool s_on = !LASTC || pre_next;
+            const unsigned s_base = !LASTC ? strip_base(cur, cc + 1) : strip_base(nxt, 0);
+            const int s_NS = s_on ? (!LASTC ? cur.NS : nxt.NS) : 0;            // 0: zero fills
+            unsigned svrun = svl + (unsigned)(wave * 8 * Cin * (int)sizeof(T));  // lane offset of this wave's piece of the step (slot t * 8 + wave)
+            int rowrun = wave * 8 + l8;                                         // ... and its strip row
+            asm volatile("" : "+v"(svrun), "+v"(rowrun));
+            const int sdst0 = __builtin_amdgcn_readfirstlane((pc ^ 1) * REG + wave * 1024);
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) {
                 const unsigned char* sw = smem + wst_off(t % 3) + (wn * WN + l16) * 128;
                 // ---- R
                 if constexpr (MIRROR) {
-                    if (wn == 1 && t == NTAPS - 1 && s_on && !(d.mirror & 2)) mirror_fix(pc ^ 1, last_cc ? nxt : cur);
+                    if (t == NTAPS - 1 && s_on && !(d.mirror & 2)) mirror_fix(pc ^ 1, LASTC ? nxt : cur);
                 }
                 u32x4_t xf[2][MT], wf[2][NT];
 #pragma unroll
@@ -568,162 +482,46 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
 #pragma unroll
                     for (int b = 0; b < MT; ++b) xf[h][b] = *reinterpret_cast<const u32x4_t*>(sx + (rt_get(t, b) ^ (unsigned)(h << 6)));
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                if (t <= NTAPS - 3) {
+                    const unsigned off = rowrun < s_NS ? svrun : 0xFFFFFFFFu;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)((lds_ptr_t)smem + sdst0 + t * 8192), 16, (int)off, (int)s_base, 0, 0);
+                    asm volatile("v_add_u32 %0, %2, %0\n\tv_add_u32 %1, 64, %1" : "+v"(svrun), "+v"(rowrun) : "s"(k64));
+                }
+                {
+                    const bool NEXT_TILE = LASTC && t >= NTAPS - 2;            // taps 0, 1 of the next tile (constant after unrolling)
+                    const int st = (t + 2) % 3;
+                    const unsigned vo0 = (NEXT_TILE && !pre_next) ? 0xFFFFFFFFu : wvl0, vo1 = (NEXT_TILE && !pre_next) ? 0xFFFFFFFFu : wvl1;
+                    lds_ptr_t dst = (lds_ptr_t)smem + wst_off(st) + wave * 1024;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(NEXT_TILE ? rs_nxt : rs_cur, (__attribute__((address_space(3))) void*)dst, 16, (int)vo0, w_run, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(NEXT_TILE ? rs_nxt : rs_cur, (__attribute__((address_space(3))) void*)(dst + NW * 1024), 16, (int)vo1, w_run, 0, 0);
+                    if (t == NTAPS - 3) {
+                        if constexpr (LASTC) w_run = w_next0;
+                        else asm volatile("s_add_u32 %0, %0, %1" : "+s"(w_run) : "s"(inc_wrap) : "scc");
+                    } else asm volatile("s_add_u32 %0, %0, %1" : "+s"(w_run) : "s"(inc_tap) : "scc");
+                }
+                if (t <= NTAPS - 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- M
-                const bool b_end = last_cc && t == NTAPS - 1;              // group B at the end of the tile: no issue, no closing barrier
-                if constexpr (MIRROR) {
-                    if (wn == 0 && t == NTAPS - 1 && s_on && !(d.mirror & 2)) mirror_fix(pc ^ 1, last_cc ? nxt : cur);
-                }
-                if (t <= NTAPS - 3) issue_strip_piece(t * NW + wave, s_base, s_NS, pc ^ 1);
-                {
-                    // group A: tap t + 2, group B: tap t + 3 - by scalar selects, no branch: the M phase stays ONE basic block, so that the
-                    // scheduler can place the DMAs between the MFMAs.  Group B at the end of the tile: zero fills into strip 0's zero rows.
-                    const bool wrapA = t + 2 >= NTAPS, wrapB = t + 3 >= NTAPS;
-                    const int tqA = wrapA ? t + 2 - NTAPS : t + 2, tqB = wrapB ? t + 3 - NTAPS : t + 3;
-                    const bool gb = wn == 1;
-                    const bool wrap = gb ? wrapB : wrapA;
-                    const bool w_on = (!(wrap && last_cc) || pre_next) && !(gb && b_end);
-                    const bool w_g2 = (wrap && last_cc) ? nxt.g2 : cur.g2;
-                    const int wti = (int)(tpk >> (gb ? 4 * tqB : 4 * tqA)) & 15;      // weight-tap index (packed: a kernel-argument load here would stall the MFMA stream)
-                    const int ccq = wrap ? (last_cc ? 0 : cc + 1) : cc;
-                    const int nb = (wrap && last_cc) ? nxt.n_base : cur.n_base;
-                    const unsigned w_so = (unsigned)__builtin_amdgcn_readfirstlane((nb * d.ldw + wti * Cin + ccq * BK) * (int)sizeof(T));
-                    const int stq = gb ? tqB % 3 : tqA % 3;
-                    const int dst0 = (gb && b_end) ? CAP * 128 : wst_off(stq) + wave * 1024;
-                    const int dst1 = (gb && b_end) ? REG + CAP * 128 : wst_off(stq) + (wave + NW) * 1024;
-                    const unsigned vo = w_on ? wvl0 : 0xFFFFFFFFu;
-                    const int so1 = (int)w_so + NW * 8 * d.ldw * (int)sizeof(T);
-                    const __amdgpu_buffer_rsrc_t rsw = w_g2 ? rsw2 : rsw1;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)((lds_ptr_t)smem + dst0), 16, (int)vo, (int)w_so, 0, 0);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)((lds_ptr_t)smem + dst1), 16, (int)vo, so1, 0, 0);
-                }
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int a = 0; a < NT; ++a)
 #pragma unroll
                         for (int b = 0; b < MT; ++b) MmaS<T>::run(wf[h][a], xf[h][b], acc[a][b]);
-                if (t <= NTAPS - 3) { __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (t <= NTAPS - 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                if constexpr (MIRROR) { if (t == NTAPS - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }      // group A's mirror-pixel writes
-                if (!(wn == 1 && b_end)) __builtin_amdgcn_s_barrier();
+                if (!(LASTC && t == NTAPS - 1 && wn == 1)) __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        } else if constexpr (PH) {
-        // ---- the phased schedule (round 4; after the guide's 256^2 eight-phase GEMM template).  A K-step (one tap, 64 channels) is
-        //   R: 16 fragment reads, the step's DMAs (strip piece, two weight pieces), the counted DMA wait, lgkmcnt(0) | barrier |
-        //   M: 32 MFMAs at raised priority | barrier.
-        // Waves 4-7 (the SIMD partners of waves 0-3) run ONE BARRIER BEHIND waves 0-3, so in every interval between two barriers one wave of
-        // each SIMD reads fragments and issues DMAs while the other owns the matrix pipe: the fragment round trip, the DMA issue and the
-        // barrier skew - what the one-barrier-per-step loop exposes in front of its MFMAs (~1650 cycles per step for 1024
-        // of MFMA) - sit behind the partner's MFMAs.  (First form: phases of one K HALF, 16 MFMAs between barriers like the template: the
-        // same launch time as the unphased loop - a barrier costs the pipe ~140 cycles whatever sits around it; hence whole steps.)
-        // Hazards (intervals I_k between barriers; group A = waves 0-3, B = waves 4-7; step s: A reads in I_2s, B in I_2s+1):
-        //   * weights of step s+2 go to stage (s+2) % 3 = the stage of step s-1, last read by B in I_2s-1 and RETIRED there (lgkmcnt(0) in
-        //     front of the barrier that ends the interval); issued by A in I_2s, by B in I_2s+1.
-        //   * a wave's DMAs of step s are waited for in step s+1's R phase, AFTER that step's own DMAs are issued, by vmcnt(3 | 2) = their
-        //     number (the same in every wave: zero fills stand in for pieces that do not exist): A in I_2s+2, B in I_2s+3; the barrier that
-        //     ends I_2s+3 publishes them; first read by A in I_2s+4.
-        //   * strip pieces of chunk c+1 (taps 0-6 of chunk c) go to the other strip region, last read in chunk c-1; landed and published
-        //     by the barrier behind tap 7's R phases; the mirror pixels are written in tap 8's R phase and retired there.
-        //   * end of tile: group B skips the closing barrier of the last step (nobody waits for those MFMAs) - the groups are level
-        //     again (equal barrier counts), the epilogues start without a wait; the scratch is [strip 1][W2]: the last chunk's strip and
-        //     the last tap's stage, neither a prefetch target (the next tile's chunk 0 and taps 0, 1 go to strip 0, W0, W1).  ncc is even
-        //     (host-checked), so a tile's last chunk is always in strip 1.
-        if (r == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the block's first strip chunk and weight tiles
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // ... and every wave's epilogue scratch reads / zero-row / mirror-pixel writes
-        __builtin_amdgcn_s_barrier();
-        if (wn == 1) __builtin_amdgcn_s_barrier();                          // group B: one barrier behind
-        const int abl = STAMP ? d.abl : 0;                                  // timing ablations (stamped build only)
-        u32x4_t xf[2][MT], wf[2][NT];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int a = 0; a < 4; ++a) { xf[h][a] = u32x4_t{0u, 0u, 0u, 0u}; wf[h][a] = u32x4_t{0u, 0u, 0u, 0u}; }
-        for (int cc = 0; cc < ncc; ++cc) {
-            const int pc = par ^ (cc & 1);
-            const unsigned char* sx = smem + pc * REG;
-            const bool last_cc = cc + 1 == ncc;
-            const bool pre_next = last_cc && nxt.valid;
-            const bool s_on = !last_cc || pre_next;
-            const unsigned s_base = !last_cc ? strip_base(cur, cc + 1) : strip_base(nxt, 0);
-            const int s_NS = s_on ? (!last_cc ? cur.NS : nxt.NS) : 0;          // 0: zero fills
-#pragma unroll
-            for (int t = 0; t < NTAPS; ++t) {
-                const bool wrap = t + 2 >= NTAPS;
-                const int t2 = wrap ? t + 2 - NTAPS : t + 2;
-                const bool w_on = !(wrap && last_cc) || pre_next;
-                const bool w_g2 = (wrap && last_cc) ? nxt.g2 : cur.g2;
-                const unsigned w_so = !wrap ? w_base(cur, t2, cc) : (!last_cc ? w_base(cur, t2, cc + 1) : w_base(nxt, t2, 0));
-                const unsigned char* sw = smem + wst_off(t % 3) + (wn * WN + l16) * 128;
-                [[maybe_unused]] unsigned long long tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0;      // STAMP: R | opening barrier | M | closing barrier
-                auto mt = [&](unsigned long long& v) {
-                    if constexpr (STAMP) { if (abl & 64) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } }
-                };
-                mt(tp0);
-                if constexpr (MIRROR) {
-                    if (t == NTAPS - 1 && s_on && !(d.mirror & 2)) mirror_fix(pc ^ 1, last_cc ? nxt : cur);
-                }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int co = ((q + 4 * h) ^ wswz) << 4;
-                    if (!(abl & 8)) {
-#pragma unroll
-                    for (int a = 0; a < NT; ++a) wf[h][a] = *reinterpret_cast<const u32x4_t*>(sw + a * 16 * 128 + co);
-                    }
-                    if (!(abl & 4)) {
-#pragma unroll
-                    for (int b = 0; b < MT; ++b) xf[h][b] = *reinterpret_cast<const u32x4_t*>(sx + (rt_get(t, b) ^ (unsigned)(h << 6)));
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                [[maybe_unused]] unsigned long long tr1 = 0, tr2 = 0, tr3 = 0;      // STAMP: inside R (no wait behind these: the phase's lgkmcnt(0) retires them)
-                auto mtn = [&](unsigned long long& v) {
-                    if constexpr (STAMP) { if (abl & 128) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } }      // (waits for the fragment reads too: the R phase serialised into its parts)
-                };
-                mtn(tr1);
-                if (!(abl & 1)) {
-                if (t <= NTAPS - 3) issue_strip_piece(t * NW + wave, s_base, s_NS, pc ^ 1);
-                issue_wph(0, w_g2, w_so, t2 % 3, w_on);
-                issue_wph(1, w_g2, w_so, t2 % 3, w_on);
-                }
-                mtn(tr2);
-                if (abl & 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if (t <= NTAPS - 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                mtn(tr3);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                mt(tp1);
-                if constexpr (STAMP) { if (abl & 128) { r1sum += tr1 - tp0; r2sum += tr2 - tr1; r3sum += tr3 - tr2; r4sum += tp1 - tr3; } }
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                mt(tp2);
-                __builtin_amdgcn_s_setprio(0);      // M at LOW priority, R at high: a waiting MFMA otherwise starves the partner wave of VALU issue slots (its address arithmetic)
-                if (!(abl & 16)) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int a = 0; a < NT; ++a)
-#pragma unroll
-                        for (int b = 0; b < MT; ++b) MmaS<T>::run(wf[h][a], xf[h][b], acc[a][b]);
-                }
-                __builtin_amdgcn_s_setprio(2);
-                mt(tp3);
-                __builtin_amdgcn_sched_barrier(0);
-                if (!(wn == 1 && last_cc && t == NTAPS - 1)) __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (STAMP) { mt(tp4); wsum += tp1 - tp0; bsum += tp2 - tp1; msum += tp3 - tp2; csum += tp4 - tp3; ++nstep; }
-            }
-        }
+        };
+        for (int cc = 0; cc + 1 < ncc; ++cc) chunk(std::false_type{}, cc);
+        chunk(std::true_type{}, ncc - 1);
         } else
         for (int cc = 0; cc < ncc; ++cc) {
             const int pc = par ^ (cc & 1);                     // region of this chunk's strip; weight stage of step t: pc ^ (t & 1)
@@ -924,16 +722,15 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
             for (int i = 0; i < 8; ++i) o[i] = i < nst ? tstamp[i] : 0ull;
             unsigned long long* o2 = d.dbg + (long)gridDim.x * NW * 8 + ((long)blockIdx.x * NW + wave) * 4;      // second table behind the stamps
             o2[0] = wsum; o2[1] = bsum; o2[2] = (unsigned long long)nstep; o2[3] = 0ull;
-            if constexpr (PH) { unsigned long long* o3 = d.dbg + (long)gridDim.x * NW * 12 + ((long)blockIdx.x * NW + wave) * 2; o3[0] = msum; o3[1] = csum;
-                unsigned long long* o4 = d.dbg + (long)gridDim.x * NW * 14 + ((long)blockIdx.x * NW + wave) * 4; o4[0] = r1sum; o4[1] = r2sum; o4[2] = r3sum; o4[3] = r4sum; }
         }
     }
 }
 
 static int g_pk_dm = 0;        // tuning hook: variant of the bf16 kernel (see the switch in uig_launch_strip_pk)
 static int g_pk_grid = 0;      // tuning hook: persistent grid size (0 = one block per CU)
-static int g_pk_abl = 0;       // diagnostic: timing ablations of the phased schedule (bits: 1 no DMAs, 2 uncounted wait, 4 / 8 no strip / weight fragment reads, 16 no MFMAs, 32 no priority)
-extern "C" void uig_debug_set_strip_pk(int dm, int grid) { g_pk_abl = dm >> 8; g_pk_dm = dm & 255; g_pk_grid = grid; }
+extern "C" void uig_debug_set_strip_pk(int dm, int grid) { g_pk_dm = dm; g_pk_grid = grid; }
+static long g_pk_phased = 0;   // launches that took the phased schedule (tests assert the variant they mean to cover)
+extern "C" long uig_debug_strip_pk_phased_count(void) { return g_pk_phased; }
 
 static int device_cus() {
     static const int n = [] {
@@ -946,7 +743,7 @@ static int device_cus() {
 
 template <typename T, int CAP, int DM, int SWZ = 1, bool LGK = true, bool STAMP = false, bool MIRROR = false, bool NORM = false, bool NOZ = false, int NISS = 8, bool PKRT = false, bool BST = false>
 static int launch_pk(const void* x, const void* wp, const float* bias, void* y, const StripDesc& d, int ntiles, hipStream_t s) {
-    const size_t smem = 2 * ((size_t)(CAP + (NOZ ? 0 : 8)) * 128 + 128 * 128) + (NORM ? (size_t)4 * 256 * 8 : 0) + (DM == 6 || DM == 7 || DM == 8 ? 128 * 128 : 0);      // NORM: (mean, rstd) of 4 images x <= 256 channels; DM 6: a third weight stage
+    const size_t smem = 2 * ((size_t)(CAP + (NOZ ? 0 : 8)) * 128 + 128 * 128) + (NORM ? (size_t)4 * 256 * 8 : 0) + (DM >= 6 && DM <= 9 ? 128 * 128 : 0);      // NORM: (mean, rstd) of 4 images x <= 256 channels; DM 6: a third weight stage
     auto kern = conv_strip_pk_kernel<T, CAP, DM, SWZ, LGK, STAMP, MIRROR, NORM, NOZ, NISS, PKRT, BST>;
     static SmemAttrOnce attr_once;
     {
@@ -982,18 +779,19 @@ int uig_launch_strip_pk(const void* x, const void* wp, const float* bias, void* 
         return launch_pk<bf16_t, 448, 5, 1, true, false, false, true>(x, wp, bias, y, d, ntiles, s);
     }
     if (dtype == UIG_BF16) {
-        // round 4: the phased schedule (DM 6): an even number of 64-channel chunks, at most 440 strip rows (the third weight stage's LDS)
-        d.abl = g_pk_abl;
-        const bool ph_ok = (d.Cin / 64) % 2 == 0 && d.need_rows <= 440 && d.bst_partial == nullptr;
-        if (g_pk_dm == 6 && ph_ok && d.dbg != nullptr && !d.mirror) return launch_pk<bf16_t, 440, 6, 1, true, true, false, false, false, 8, true>(x, wp, bias, y, d, ntiles, s);   // stamped
-        if (g_pk_dm == 8 && ph_ok && d.dbg == nullptr) {
-            if (d.mirror) return launch_pk<bf16_t, 440, 8, 1, true, false, true, false, false, 8, true>(x, wp, bias, y, d, ntiles, s);
-            return launch_pk<bf16_t, 440, 8, 1, true, false, false, false, false, 8, true>(x, wp, bias, y, d, ntiles, s);      // packed row table: its unpacking sits in the R phase, which has slack
-        }
-        if (g_pk_dm == 7 && ph_ok && d.dbg == nullptr && !d.mirror) return launch_pk<bf16_t, 440, 7, 1, true, false, false, false, false, 8, true>(x, wp, bias, y, d, ntiles, s);
-        if (g_pk_dm == 6 && ph_ok && d.dbg == nullptr) {
-            if (d.mirror) return launch_pk<bf16_t, 440, 6, 1, true, false, true, false, false, 8, true>(x, wp, bias, y, d, ntiles, s);      // packed row table: no scratch
-            return launch_pk<bf16_t, 440, 6, 1, true, false, false, false, false, 8, false>(x, wp, bias, y, d, ntiles, s);
+        // round 4: the phased schedule (DM 9, the default where it applies; g_pk_dm = 5 selects round 3's schedule for A/B): an even number of
+        // 64-channel chunks, at most 440 strip rows (the third weight stage's LDS), weight-tap index affine in the tap (running offset)
+        d.wt_a = d.tap[0] >> 16; d.wt_b = (d.tap[1] >> 16) - (d.tap[0] >> 16);
+        bool wt_affine = true;
+        for (int t = 0; t < 9; ++t) wt_affine = wt_affine && (d.tap[t] >> 16) == d.wt_a + d.wt_b * t;
+        const bool ph_ok = (d.Cin / 64) % 2 == 0 && d.need_rows <= 440 && d.bst_partial == nullptr && wt_affine;
+        if (ph_ok && (g_pk_dm == 0 || g_pk_dm == 9) && (d.dbg == nullptr || !d.mirror)) ++g_pk_phased;
+        if (ph_ok && (g_pk_dm == 0 || g_pk_dm == 9)) {
+            if (d.dbg != nullptr && !d.mirror) return launch_pk<bf16_t, 440, 9, 1, true, true, false, false, false, 8, false>(x, wp, bias, y, d, ntiles, s);   // coarse stamps (scripts/stamp_lean.py)
+            if (d.dbg == nullptr) {
+                if (d.mirror) return launch_pk<bf16_t, 440, 9, 1, true, false, true, false, false, 8, false>(x, wp, bias, y, d, ntiles, s);
+                return launch_pk<bf16_t, 440, 9, 1, true, false, false, false, false, 8, false>(x, wp, bias, y, d, ntiles, s);
+            }
         }
         if (d.mirror) {
             if (d.dbg != nullptr) return launch_pk<bf16_t, 448, 0, 1, true, true, true>(x, wp, bias, y, d, ntiles, s);

@@ -29,6 +29,7 @@ SIGNATURES = {
     "uig_debug_set_strip_wide": (None, [_i]),
     "uig_debug_set_mirror": (None, [_i]),
     "uig_debug_set_strip_pk": (None, [_i, _i]),
+    "uig_debug_strip_pk_phased_count": (C.c_long, []),
     "uig_debug_set_rowstrip": (None, [_i]),
     "uig_debug_set_strip_stages": (None, [_i]),
     "uig_debug_set_strip_small": (None, [_i]),
