@@ -242,6 +242,75 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
         }
     };
 
+    // The same mirror pixels for the phased schedule, where they sit in the R phase of a chunk's last step and every instruction of
+    // that phase counts (mirror_fix above is ~320 instructions of index arithmetic per wave; this form ~45): W is 64 (host-checked), so a
+    // thread's item - pixel and 16-byte chunk - and its swizzled byte offsets inside a strip line are functions of the thread id alone:
+    //   threads 0-95: column mirror (line r = px % 6, side = px / 6, chunk k) of the strip's six lines;
+    //   edge tiles, all 512 threads: line-mirror pixel c = tid / 8, chunk k: both source lines and the destination share the offset
+    //   c * 128 + swizzle(c, k) (the slots NS + 48 + c, rA * 64 + c, rB * 64 + c all have c's low three bits);
+    //   edge tiles, threads 0-15: the line mirror's own two column mirrors (four-pixel sums) - the general form, 2 pixels per tile.
+    // Same sums in the same order, one rounding: bitwise the result of mirror_fix.
+    // (in the K loop the column mirrors' two source chunks are requested BEFORE the step's 16 fragment reads and summed behind them -
+    // `pre` / `mid`: the LDS round trip of the sources would otherwise stand alone in front of the reads)
+    [[maybe_unused]] auto mirror_fix_lean = [&](int region, const Tile& t, auto&& between) {
+        if constexpr (MIRROR) {
+            unsigned char* sb = smem + region * REG;
+            const int nrows = t.NS >> 6;
+            const bool top = t.ti == 0, edge = top || t.ti == tpi - 1;
+            auto sum2 = [&](int a0, int a1, int ao) {
+                float f[8], g[8];
+                chunk_to_f32<T>(*reinterpret_cast<const u32x4_t*>(sb + a0), f);
+                chunk_to_f32<T>(*reinterpret_cast<const u32x4_t*>(sb + a1), g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += g[e];
+                *reinterpret_cast<u32x4_t*>(sb + ao) = f32_to_chunk<T>(f);
+            };
+            int tid_m = tid;
+            asm volatile("" : "+v"(tid_m));                     // opaque: nothing derived from it may be hoisted out of the K loop (registers)
+            const int k = tid_m & 7, px = tid_m >> 3;
+            {
+                const bool side = px >= 6;
+                const int r = side ? px - 6 : px;
+                const bool mine = tid_m < 96 && r < nrows;
+                const int c0 = side ? d.W - 3 : 2, c1 = side ? d.W - 1 : 0, sc = 8 * r + (side ? 5 : 2);
+                // every thread reads (threads without an item: chunk 0 of the region - harmless) so that the reads are not under a branch
+                const int a0 = mine ? (r * 64 + c0) * 128 + (((k + (c0 & 6)) & 7) << 4) : 0;
+                const int a1 = mine ? (r * 64 + c1) * 128 + (((k + (c1 & 6)) & 7) << 4) : 0;
+                const u32x4_t v0 = *reinterpret_cast<const u32x4_t*>(sb + a0), v1 = *reinterpret_cast<const u32x4_t*>(sb + a1);
+                between();
+                if (mine) {
+                    float f[8], g[8];
+                    chunk_to_f32<T>(v0, f); chunk_to_f32<T>(v1, g);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += g[e];
+                    *reinterpret_cast<u32x4_t*>(sb + (t.NS + sc) * 128 + (((k + (sc & 6)) & 7) << 4)) = f32_to_chunk<T>(f);
+                }
+            }
+            if (edge) {                                                             // block-uniform
+                const int rA = (top ? 2 : d.H - 3) - t.lo, rB = (top ? 0 : d.H - 1) - t.lo;
+                const int base = px * 128 + (((k + (px & 6)) & 7) << 4);            // px = c < 64
+                sum2(rA * 8192 + base, rB * 8192 + base, (t.NS + 48) * 128 + base);
+                if (tid_m < 16) {                                                   // c = 64, 65: columns 2 + 0 / W-3 + W-1 of both lines
+                    const int cc2 = tid_m >> 3;
+                    const int ca = cc2 == 0 ? 2 : d.W - 3, cb = cc2 == 0 ? 0 : d.W - 1, x = cc2 == 0 ? 66 : 69;
+                    auto ad = [&](int slot) -> int { return slot * 128 + (((k + (slot & 6)) & 7) << 4); };
+                    float f[8], g[8];
+                    chunk_to_f32<T>(*reinterpret_cast<const u32x4_t*>(sb + ad(rA * 64 + ca)), f);
+                    chunk_to_f32<T>(*reinterpret_cast<const u32x4_t*>(sb + ad(rB * 64 + ca)), g);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += g[e];
+                    chunk_to_f32<T>(*reinterpret_cast<const u32x4_t*>(sb + ad(rA * 64 + cb)), g);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += g[e];
+                    chunk_to_f32<T>(*reinterpret_cast<const u32x4_t*>(sb + ad(rB * 64 + cb)), g);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += g[e];
+                    *reinterpret_cast<u32x4_t*>(sb + ad(t.NS + 48 + x)) = f32_to_chunk<T>(f);
+                }
+            }
+        }
+    };
+
     // ---- NORM: (x - mean) * rstd, activation, one rounding - on ONE strip piece (8 rows x 128 B = one 16-byte chunk per lane), in place,
     //      by the wave that DMA'd it (its own vmcnt(0) wait orders the landed piece before these reads: no barrier needed).  Lane L holds
     //      row 8j + L/8, physical slot L%8 = channel chunk (L%8 - (row & 6)) & 7 of the 64-channel K chunk cc: the same chunk for every
@@ -394,7 +463,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
             if (r == 0 && !(d.mirror & 4)) {                                       // the block's first chunk: nothing ran in front of it to hide this behind
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                mirror_fix(0, cur);
+                if constexpr (PH) mirror_fix_lean(0, cur, [] {}); else mirror_fix(0, cur);
             }
         }
         if constexpr (NORM) {
@@ -470,18 +539,28 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
             for (int t = 0; t < NTAPS; ++t) {
                 const unsigned char* sw = smem + wst_off(t % 3) + (wn * WN + l16) * 128;
                 // ---- R
-                if constexpr (MIRROR) {
-                    if (t == NTAPS - 1 && s_on && !(d.mirror & 2)) mirror_fix(pc ^ 1, LASTC ? nxt : cur);
-                }
                 u32x4_t xf[2][MT], wf[2][NT];
+                // the step's 16 fragment reads in two parts (14 + 2): the mirror-pixel step keeps its two source chunks in the registers of the
+                // last two fragments while the first 14 are in flight (no registers of its own: the kernel sits at 251 of 256)
+                auto frag_reads = [&](int part) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int co = ((q + 4 * h) ^ wswz) << 4;
+                    for (int h = 0; h < 2; ++h) {
+                        const int co = ((q + 4 * h) ^ wswz) << 4;
 #pragma unroll
-                    for (int a = 0; a < NT; ++a) wf[h][a] = *reinterpret_cast<const u32x4_t*>(sw + a * 16 * 128 + co);
+                        for (int a = 0; a < NT; ++a)
+                            if ((h == 1 && a == NT - 1) == (part == 1)) wf[h][a] = *reinterpret_cast<const u32x4_t*>(sw + a * 16 * 128 + co);
 #pragma unroll
-                    for (int b = 0; b < MT; ++b) xf[h][b] = *reinterpret_cast<const u32x4_t*>(sx + (rt_get(t, b) ^ (unsigned)(h << 6)));
+                        for (int b = 0; b < MT; ++b)
+                            if ((h == 1 && b == MT - 1) == (part == 1)) xf[h][b] = *reinterpret_cast<const u32x4_t*>(sx + (rt_get(t, b) ^ (unsigned)(h << 6)));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                bool fixed = false;
+                if constexpr (MIRROR) {
+                    if (t == NTAPS - 1 && s_on && !(d.mirror & 2)) { mirror_fix_lean(pc ^ 1, LASTC ? nxt : cur, [&] { frag_reads(0); }); fixed = true; }
                 }
+                if (!fixed) frag_reads(0);
+                frag_reads(1);
                 __builtin_amdgcn_sched_barrier(0);
                 if (t <= NTAPS - 3) {
                     const unsigned off = rowrun < s_NS ? svrun : 0xFFFFFFFFu;
