@@ -441,7 +441,7 @@ def dominant_kernel_roofline(u, torch, dev, dtype, nimg, hw, iters, fp8=False):
     eb = 1 if fp8 else (2 if dtype == torch.bfloat16 else 4)      # operand bytes per element (the output is bf16 on the fp8 path)
     alg = nimg * hw * hw * 256 * (eb + (2 if fp8 else eb)) + 2 * 256 * 2304 * eb
     kid = u.lib.lib().uig_debug_last_conv_kernel() if not fp8 else -1
-    kname = {-1: "conv_strip_fp8_kernel<448> (MX e4m3 v_mfma_scale_f32_16x16x128, 256x128 tiles, persistent blocks) [%s operands]",u.lib.K_STRIP_PK: "conv_strip_pk_kernel<%s,448> (256x128 tiles, persistent blocks)", u.lib.K_STRIP256: "conv_strip_kernel<%s,256,128>"}.get(kid, "kernel id %d <%%s>" % kid)
+    kname = {-1: "conv_strip_fp8_kernel<448> (MX e4m3 v_mfma_scale_f32_16x16x128, 256x128 tiles, persistent blocks) [%s operands]",u.lib.K_STRIP_PK: "conv_strip_pk_kernel<%s,440,phased> (256x128 tiles, persistent blocks, two wave groups one barrier apart)", u.lib.K_STRIP256: "conv_strip_kernel<%s,256,128>"}.get(kid, "kernel id %d <%%s>" % kid)
     return {"kernel": (kname + " conv3x3 256->256 reflect, paired G_A|G_B launch (ResBlock fwd, emitting the InstanceNorm statistics as in the step)") % ("fp8" if fp8 else "bf16" if dtype == torch.bfloat16 else "f32"),
             "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
             "frac": round(ach / peak, 4), "traffic": None, "traffic_from_profile": traffic_from_profile, "algorithmic_bytes": alg,
