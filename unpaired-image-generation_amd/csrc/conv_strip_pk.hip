@@ -17,6 +17,10 @@
 //     the rotation is conflict-free at every shift (bank analysis in DESIGN.md §3.2).
 //   * DMA issue is spread between the MFMA groups of a K-step (DM = 1) instead of all 8 waves issuing their 3 pieces at the
 //     top of the step while the matrix pipe idles.
+// Round 4: the K loop of the bf16 kernel runs a PHASED schedule by default where the shape allows (DM = 9: two wave groups one barrier
+// apart, three weight stages, counted LDS-DMA waits - the comment at the head of that loop); round 3's loop (DM = 5, four
+// issuing waves, next step's strip fragments read behind this step's MFMAs) serves the NORM / BST / 512-row / odd-chunk-count launches
+// and stays selectable for A/B (uig_debug_set_strip_pk(5, 0)).
 #include "conv_strip_desc.h"
 #include <algorithm>
 #include <type_traits>
