@@ -1,6 +1,7 @@
 """GPU parity tests: every HIP op (forward AND backward) through the C ABI vs the CPU oracle (stock torch ops) on the
 same seeded inputs.  fp32 path: exact-f32 MFMA, tight tolerance.  bf16 path: compared with the oracle evaluated on
 bf16-rounded operands (fp32 accumulate), tolerance = a few bf16 ulps of the output scale (stated per test)."""
+import os
 import zlib
 
 import numpy as np
@@ -1281,13 +1282,14 @@ def test_strip64_small_grid_variant_equals_128_tile_kernel(S, cin, cout, B, grou
     (16, 64, 64, 128, 128, 0, "reflect"),     # two 64-channel chunks, one channel tile
     (16, 64, 32, 256, 256, 8, "zero"),       # 32-pixel-wide map: 10-line strips (320 rows)
     (12, 32, 64, 128, 256, 0, "reflect"),     # 32 x 64 map, chunk count 2, two channel tiles
-], ids=["bench16", "single8", "three-tiles", "uneven9", "grid192-zero", "c128", "w32-zero", "h32-c128"])
+    (40, 64, 64, 256, 256, 20, "reflect"),    # five tiles per block
+], ids=["bench16", "single8", "three-tiles", "uneven9", "grid192-zero", "c128", "w32-zero", "h32-c128", "five-tiles"])
 def test_strip_persistent_phased_schedule_equals_round3_schedule_bitwise(B, H, W, cin, cout, group, pm):
     """Round 4: the persistent strip kernel's K loop runs the PHASED schedule by default (conv_strip_pk.hip, DM 9: two wave groups one
     barrier apart, three weight stages, counted LDS-DMA waits, the third stage in what used to be spare LDS) - a new synchronisation
     structure.  Same arithmetic in the same order as round 3's loop, so every output must be BITWISE equal to it: forward + fused
     InstanceNorm partial statistics, the mirror-pixel input gradient with the skip gradient (64-wide maps) or the plain transposed
-    gather.  Race screen: 12 launches per shape on fresh random data, over shapes that vary tiles per block (1, 2, 3, mixed), grid
+    gather.  Race screen: 12 launches per shape on fresh random data (UIG_RACE_REPS for more), over shapes that vary tiles per block (1, 2, 3, 5, mixed), grid
     size, chunk count, map width, padding and pairing.  (The oracle parity of both schedules: test_strip_persistent_256x128_bench_shape
     and the step tests.)"""
     u, ops, networks = _mods()
@@ -1300,7 +1302,7 @@ def test_strip_persistent_phased_schedule_equals_round3_schedule_bitwise(B, H, W
     pair_g = (ls[1].wp_dgrad, None, group) if group else None
     gen = torch.Generator("cuda").manual_seed(17)
     try:
-        for rep in range(12):
+        for rep in range(int(os.environ.get("UIG_RACE_REPS", "12"))):      # (a one-off screen of 300 launches per shape: clean, round 4)
             x = (torch.rand(B, H, W, cin, device="cuda", generator=gen) * 2 - 1).to(dt)
             dy = (torch.randn(B, H, W, cout, device="cuda", generator=gen) * 0.5).to(dt)
             res = (torch.randn(B, H, W, cin, device="cuda", generator=gen) * 0.5).to(dt)
