@@ -445,7 +445,10 @@ def dominant_kernel_roofline(u, torch, dev, dtype, nimg, hw, iters, fp8=False):
     return {"kernel": (kname + " conv3x3 256->256 reflect, paired G_A|G_B launch (ResBlock fwd, emitting the InstanceNorm statistics as in the step)") % ("fp8" if fp8 else "bf16" if dtype == torch.bfloat16 else "f32"),
             "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
             "frac": round(ach / peak, 4), "traffic": None, "traffic_from_profile": traffic_from_profile, "algorithmic_bytes": alg,
-            "avg_us": round(us, 2), "gemm": f"M={nimg * hw * hw} N=256 K=2304 (2 weight sets)", "flops_per_launch": flops}
+            "avg_us": round(us, 2), "gemm": f"M={nimg * hw * hw} N=256 K=2304 (2 weight sets)", "flops_per_launch": flops,
+            "clock_note": "peak = nominal 2.5 PFLOP/s at 2.4 GHz; this launch loops at the package power limit (rocm-smi 1350-1360 W of 1400) and the part "
+                          "lowers the shader clock to 2.07-2.24 GHz under it; register-resident bf16 MFMAs on random operands sustain 0.81 of nominal "
+                          "(scripts/probes/mfma_power.hip); in-kernel stamps: 1182-1190 cycles per K-step for 1024 of MFMA (DESIGN.md 5.000)"}
 
 
 def cpu_baseline(torch, size, batch):
