@@ -13,7 +13,8 @@ lib.uig_debug_set_strip_pk(DM, 0)
 l1 = networks.ConvLayer("conv", 256, 256, 3, 1, 1, "reflect", dtype=dt, device="cuda"); l1.repack()
 l2 = networks.ConvLayer("conv", 256, 256, 3, 1, 1, "reflect", dtype=dt, device="cuda"); l2.repack()
 x = (torch.rand(B, 64, 64, 256, device="cuda") * 2 - 1).to(dt)
-f = lambda: ops.conv_forward(l1.spec, x, l1.wp_fwd, l1.bias, pair=(l2.wp_fwd, l2.bias, B // 2), want_in_stats=True)
+STATS = "nostats" not in sys.argv      # `nostats`: the same launch without the fused InstanceNorm statistics (what they cost the epilogue)
+f = lambda: ops.conv_forward(l1.spec, x, l1.wp_fwd, l1.bias, pair=(l2.wp_fwd, l2.bias, B // 2), want_in_stats=STATS)
 def t(n=200):
     for _ in range(20): f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -37,6 +38,7 @@ k0, k1 = st[..., 2] - st[..., 1], st[..., 7] - st[..., 6]
 tot = st[..., 7].amax(dim=1) - st[..., 0].amin(dim=1)      # entry -> end of the second K loop, per block
 print(f"DM {DM} B={B}: product build {us:.1f} us, stamped build {us_st:.1f} us per launch")
 print(f"  K loop tile 0: {float(k0.median()):.0f} cycles = {float(k0.median()) / 36:.0f} per step; tile 1: {float(k1.median()):.0f} = {float(k1.median()) / 36:.0f} per step")
+print(f"  epilogue of tile 0: accumulators -> LDS {float((st[..., 4] - st[..., 3]).median()):.0f}, rows -> statistics + stores {float((st[..., 5] - st[..., 4]).median()):.0f} cycles (stamps 3 / 4 / 5)")
 print(f"  prologue (entry -> K start): {float((st[..., 1] - st[..., 0]).median()):.0f}; between the K loops: {float((st[..., 6] - st[..., 2]).median()):.0f}; entry -> end of K loop 1: {float(tot.median()):.0f} cycles")
 print(f"  => if the stamped launch is ~{us_st:.1f} us and ~{float(tot.median()) + 7500:.0f} cycles long: clock ~{(float(tot.median()) + 7500) / us_st / 1e3:.2f} GHz")
 lib.uig_debug_set_strip_pk(0, 0)
