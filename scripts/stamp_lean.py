@@ -39,6 +39,8 @@ tot = st[..., 7].amax(dim=1) - st[..., 0].amin(dim=1)      # entry -> end of the
 print(f"DM {DM} B={B}: product build {us:.1f} us, stamped build {us_st:.1f} us per launch")
 print(f"  K loop tile 0: {float(k0.median()):.0f} cycles = {float(k0.median()) / 36:.0f} per step; tile 1: {float(k1.median()):.0f} = {float(k1.median()) / 36:.0f} per step")
 print(f"  epilogue of tile 0: accumulators -> LDS {float((st[..., 4] - st[..., 3]).median()):.0f}, rows -> statistics + stores {float((st[..., 5] - st[..., 4]).median()):.0f} cycles (stamps 3 / 4 / 5)")
+sm = buf[NB * 8 * 8:NB * 8 * 12].view(NB, 8, 4).double()[ok]
+print(f"  prologue in parts (cycles from entry): first DMAs issued {float(sm[..., 0].median()):.0f}, row table built {float(sm[..., 1].median()):.0f}, accumulators initialised = K start {float((st[..., 1] - st[..., 0]).median()):.0f}, first DMAs landed {float(sm[..., 2].median()):.0f}")
 print(f"  prologue (entry -> K start): {float((st[..., 1] - st[..., 0]).median()):.0f}; between the K loops: {float((st[..., 6] - st[..., 2]).median()):.0f}; entry -> end of K loop 1: {float(tot.median()):.0f} cycles")
 print(f"  => if the stamped launch is ~{us_st:.1f} us and ~{float(tot.median()) + 7500:.0f} cycles long: clock ~{(float(tot.median()) + 7500) / us_st / 1e3:.2f} GHz")
 lib.uig_debug_set_strip_pk(0, 0)

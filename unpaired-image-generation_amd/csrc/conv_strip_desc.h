@@ -19,6 +19,7 @@ struct StripDesc {
     const void* border_add;  // optional: bord[B][8][S][ldc] of uig_reflect3x3_dgrad_border, added to rows 1 / H-2 and cols 1 / W-2
     unsigned long long* dbg; // diagnostic build only (STAMP): per-wave cycle sums {wait+barrier, DMA issue, reads+MFMA, total}
     int wo_magic;            // persistent kernel: ceil(2^20 / Wo), set by uig_launch_strip_pk
+    unsigned long long mg_ntn, mg_tpi, mg_wo;      // persistent kernel (round 4): ceil(2^32 / d) for d = channel tiles, tiles per image, Wo: n / d = (n * mg) >> 32 for n * d < 2^32 (get_tile's four divisions were ~1.4 k cycles of scalar reciprocal sequences in front of the block's first DMA)
     // optional: statistics of the InstanceNorm BACKWARD that consumes this launch's output as its dy (input-gradient launches):
     // bst_x = that norm's saved input (shape of y), bst_stats = its (mean, rstd) [B][ldc][2], bst_act / bst_slope its activation;
     // bst_partial [B][HoWo/64][Nstore][2] receives (sum g, sum g * xhat), g = dy * act'(xhat), per 64-pixel slab - what the

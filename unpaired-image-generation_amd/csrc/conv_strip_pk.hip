@@ -105,12 +105,13 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
         if (!t.valid) return t;
         const int xcd = o & 7, qq = nwg >> 3, rr = nwg & 7;      // bijective XCD remap inside the round (T1)
         const int bid = base + (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (o >> 3);
-        t.n_base = (bid % ntn) * BN;
-        const int mtile = bid / ntn;
-        t.img = mtile / tpi; t.ti = mtile - t.img * tpi; t.p0 = t.ti * BM;
+        auto mdiv = [](int n, unsigned long long mg) -> int { return (int)(((unsigned long long)(unsigned)n * mg) >> 32); };      // n / d by the host's magic (conv_strip_desc.h)
+        const int mtile = mdiv(bid, d.mg_ntn);
+        t.n_base = (bid - mtile * ntn) * BN;
+        t.img = mdiv(mtile, d.mg_tpi); t.ti = mtile - t.img * tpi; t.p0 = t.ti * BM;
         const int p_last = min(t.p0 + BM, HoWo) - 1;
-        t.lo = max(0, t.p0 / d.Wo + d.dh_min);
-        const int hi = min(d.H - 1, p_last / d.Wo + d.dh_max);
+        t.lo = max(0, mdiv(t.p0, d.mg_wo) + d.dh_min);
+        const int hi = min(d.H - 1, mdiv(p_last, d.mg_wo) + d.dh_max);
         t.NS = (hi - t.lo + 1) * d.W;
         t.g2 = d.wp2 != nullptr && t.img >= d.group_images;
         return t;
@@ -375,6 +376,8 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
     if (!cur.valid) return;                                    // block-uniform (never taken: the grid is <= the tile count)
     __syncthreads();                                           // zero rows written (no DMA in flight yet)
     issue_first(cur, 0);
+    [[maybe_unused]] unsigned long long pst0 = 0;              // STAMP, phased schedule: the prologue in parts (entry -> DMAs issued -> row table -> accumulators)
+    if constexpr (STAMP && PH) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pst0) :: "memory"); wsum = pst0 - tstamp[0]; __builtin_amdgcn_sched_barrier(0); }
 
     // ---- per-lane row table: LDS byte address (within a strip buffer, K half 0) of the B-operand row of output pixel
     //      (tile row wm*64 + b*16 + l16) displaced by tap t; half 1 of the 128-byte row is address ^ 64.
@@ -405,7 +408,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
     // the address is kept SEPARABLE: W is a multiple of 16 (host-checked), hence the swizzle term of slot hv + wv depends on wv
     // only and address(i, j) = A_i + B_j: 3 + 3 values per pixel group, one add and one select per table entry (the first form
     // swizzled each of the 36 entries: ~1000 VALU instructions, 10k cycles of prologue by the stamps; 23k with the mirror cases).
-    auto build_rt = [&](const Tile& tl) {
+    auto build_rt = [&](const Tile& tl, int half = -1) {        // half = 0 / 1: only the pixel groups b = 2 half, 2 half + 1 (the SIMD partner builds the others)
         const bool refl = d.pad_mode == UIG_PAD_REFLECT;
         const int ho0 = tl.p0 / d.Wo, rem0 = tl.p0 - ho0 * d.Wo;              // scalar
         auto swz = [&](int x) -> int { return (SWZ ? ((q + (x & 6)) & 7) : (q ^ ((x >> 1) & 7))) << 4; };   // x: slot index mod 16
@@ -414,6 +417,7 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
         for (int i = 0; i < 3; ++i) { dhs[i] = (d.tap[3 * i] & 255) - 128; dws[i] = ((d.tap[i] >> 8) & 255) - 128; }
 #pragma unroll
         for (int b = 0; b < MT; ++b) {
+            if (half >= 0 && (b >> 1) != half) continue;                        // wave-uniform
             const int pr = rem0 + wm * WM + b * 16 + l16;                       // < Wo + 256
             const int dho = (pr * d.wo_magic) >> 20;                            // pr / Wo (exact: host-checked range)
             const int ho = ho0 + dho, wo = pr - dho * d.Wo;
@@ -462,7 +466,43 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
     int par = 0;                                               // region holding chunk 0 of the current tile
     for (int r = 0;; ++r) {
         const Tile nxt = get_tile(r + 1);
-        if (cur.ti != rt_ti) { build_rt(cur); rt_ti = cur.ti; }
+        if (cur.ti != rt_ti) {
+            if constexpr (PH && !PKRT) {
+                // Waves w and w + 4 (SIMD partners, the same 64 pixel rows) hold the SAME table, and building it is ~1000 dependent
+                // instructions that one wave executes at ~5 cycles apiece whether or not its partner does the same beside it (stamps:
+                // 5.5 k cycles of the block's prologue).  Each wave builds HALF of it (two of the four 16-pixel groups) and hands that
+                // half to its partner through the LDS: two 16-bit entries per dword, 9 x 256 B per half, in wave w's own epilogue-scratch
+                // area of strip 1 (free here: no DMA of the tile's first chunk or weight tiles goes there, the waves' previous
+                // epilogues are over).
+                unsigned char* xb = smem + REG + wm * SCRW;
+                build_rt(cur, wn);
+                {
+                    unsigned pk[NTAPS];
+#pragma unroll
+                    for (int t = 0; t < NTAPS; ++t) pk[t] = wn == 0 ? (rtw[4 * t] | (rtw[4 * t + 1] << 16)) : (rtw[4 * t + 2] | (rtw[4 * t + 3] << 16));
+                    unsigned char* mine = xb + wn * 2560;
+                    *reinterpret_cast<u32x4_t*>(mine + lane * 16) = u32x4_t{pk[0], pk[1], pk[2], pk[3]};
+                    *reinterpret_cast<u32x4_t*>(mine + 1024 + lane * 16) = u32x4_t{pk[4], pk[5], pk[6], pk[7]};
+                    *reinterpret_cast<unsigned*>(mine + 2048 + lane * 4) = pk[8];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                {
+                    const unsigned char* theirs = xb + (wn ^ 1) * 2560;
+                    const u32x4_t v0 = *reinterpret_cast<const u32x4_t*>(theirs + lane * 16), v1 = *reinterpret_cast<const u32x4_t*>(theirs + 1024 + lane * 16);
+                    const unsigned v2 = *reinterpret_cast<const unsigned*>(theirs + 2048 + lane * 4);
+#pragma unroll
+                    for (int t = 0; t < NTAPS; ++t) {
+                        const unsigned v = t < 4 ? v0[t] : (t < 8 ? v1[t - 4] : v2);
+                        if (wn == 0) { rtw[4 * t + 2] = v & 0xffffu; rtw[4 * t + 3] = v >> 16; }
+                        else { rtw[4 * t] = v & 0xffffu; rtw[4 * t + 1] = v >> 16; }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the area is this wave pair's until the next epilogue)
+                }
+            } else build_rt(cur);
+            rt_ti = cur.ti;
+        }
+        if constexpr (STAMP && PH) { if (r == 0) { __builtin_amdgcn_sched_barrier(0); unsigned long long tt; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory"); bsum = tt - tstamp[0]; __builtin_amdgcn_sched_barrier(0); } }
         if constexpr (MIRROR) {
             if (r == 0 && !(d.mirror & 4)) {                                       // the block's first chunk: nothing ran in front of it to hide this behind
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -482,6 +522,9 @@ void conv_strip_pk_kernel(const T* __restrict__ x, const T* __restrict__ wp1, co
         strip_init_acc<MT, NT, WN>(acc, bias, d.Nrows, cur.n_base, wn, lane);
 
         stamp();                                               // 1 / 4: K loop starts
+        if constexpr (STAMP && PH) {                            // (+ the wait for the block's first DMAs, which the product build does behind this point)
+            if (r == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); unsigned long long tt; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory"); nstep = (int)(tt - tstamp[0]); __builtin_amdgcn_sched_barrier(0); }
+        }
         [[maybe_unused]] u32x4_t xn[MT];                       // DM == 5: the NEXT step's strip fragments of K half 0, read behind this step's MFMAs
         if constexpr (DM == 9) {
         // ---- the phased schedule (round 4; after the guide's 256^2 eight-phase GEMM template).  A K-step (one tap, 64 channels) of a wave is
@@ -853,6 +896,13 @@ int uig_launch_strip_pk(const void* x, const void* wp, const float* bias, void* 
     d.wo_magic = ((1 << 20) + d.Wo - 1) / d.Wo;             // (pr * magic) >> 20 == pr / Wo for pr < Wo + 256 <= 768 (pr * (magic * Wo - 2^20) < 2^20)
     const int tpi = (d.Ho * d.Wo + 255) / 256;
     const int ntiles = d.B * tpi * (d.Nrows / 128);
+    {   // (n * ceil(2^32 / dv)) >> 32 == n / dv while n * dv < 2^32: n < tiles (bid, mtile) or pixels of a map (p0, p_last) - checked here
+        auto mg = [](unsigned dv) -> unsigned long long { return ((1ull << 32) + dv - 1) / dv; };
+        const unsigned ntn_ = (unsigned)(d.Nrows / 128);
+        if ((unsigned long long)ntiles * std::max(ntn_, (unsigned)tpi) >= (1ull << 32) || (unsigned long long)d.Ho * d.Wo * d.Wo >= (1ull << 32))
+            return uig_set_error(-1, "conv_strip_pk: launch too large for the tile index arithmetic (%d tiles, %d x %d map)", ntiles, d.Ho, d.Wo);
+        d.mg_ntn = mg(ntn_); d.mg_tpi = mg((unsigned)tpi); d.mg_wo = mg((unsigned)d.Wo);
+    }
     if (d.wide512) {                  // 449..512 strip rows: the no-zero-row variant (host-checked: reflection padding, whole tiles, plain forward)
         if (dtype != UIG_BF16) return uig_set_error(-1, "conv_strip_pk: the 512-row strip is a bf16 path");
         return launch_pk<bf16_t, 512, 5, 1, true, false, false, false, true>(x, wp, bias, y, d, ntiles, s);
